@@ -1,0 +1,231 @@
+/* orbx — C ABI of the MI355X ORB front-end (extraction + binary matching).
+ *
+ * This is the boundary a host program binds instead of the reference's C++
+ * classes ORB_SLAM2::ORBextractor and ORB_SLAM2::ORBmatcher.  Plain pointers
+ * and sizes only; no exceptions cross it.  Every function that computes runs
+ * HIP kernels on one MI355X; there is no CPU fallback: without a usable HIP
+ * device orbx_create / the orbm_* calls return ORBX_ERR_NO_DEVICE.
+ *
+ * Conventions
+ *   - return value: 0 (ORBX_OK) or a negative orbx_status;
+ *     orbx_last_error() gives a thread-local message for the last failure.
+ *   - outputs are caller-allocated with explicit capacities.
+ *   - mem_space says where the caller's image / output pointers live.
+ *   - one handle = one HIP stream + its scratch memory.  A handle is not
+ *     thread-safe; independent handles may be used concurrently (the reference
+ *     uses one extractor object per camera, src/Tracking.cc:213-221, and two
+ *     objects from two threads for stereo, src/Frame.cc:122-125).
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum orbx_status {
+    ORBX_OK = 0,
+    ORBX_ERR_INVALID = -1,   /* bad argument */
+    ORBX_ERR_NO_DEVICE = -2, /* no HIP device / HIP runtime failure at start-up */
+    ORBX_ERR_HIP = -3,       /* a HIP call failed */
+    ORBX_ERR_CAPACITY = -4,  /* caller capacity or configured limit too small */
+    ORBX_ERR_UNSUPPORTED = -5
+} orbx_status;
+
+enum { ORBX_MEM_HOST = 0, ORBX_MEM_DEVICE = 1 };
+
+/* Layout-identical to cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle,
+ * response, octave, class_id.  Replaces the std::vector<cv::KeyPoint> argument
+ * of ORBextractor::operator() (reference include/ORBextractor.h:46-48). */
+typedef struct orbx_keypoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} orbx_keypoint;
+
+/* Constructor arguments of ORBextractor (reference include/ORBextractor.h:38-39,
+ * read from YAML at src/Tracking.cc:201-209) plus device-side sizing. */
+typedef struct orbx_config {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t max_width;    /* largest image width the handle will see */
+    int32_t max_height;   /* largest image height */
+    int32_t max_batch;    /* frames processed per internal pass (scratch is sized for this) */
+    int32_t device;       /* HIP device ordinal */
+    int32_t blur_variant; /* 0: Gaussian taps {18,34,49,55,49,34,18}; 1: {18,34,48,56,48,34,18} */
+} orbx_config;
+
+typedef struct orbx_handle orbx_handle;
+
+const char* orbx_last_error(void);
+const char* orbx_version(void);
+
+/* ORBextractor::ORBextractor (reference src/ORBextractor.cc:399-466). */
+int orbx_create(const orbx_config* cfg, orbx_handle** out);
+void orbx_destroy(orbx_handle* h);
+
+/* Run the handle's kernels on an existing hipStream_t (NULL restores the
+ * handle's own stream). */
+int orbx_set_stream(orbx_handle* h, void* hip_stream);
+int orbx_synchronize(orbx_handle* h);
+
+/* Upper bound on keypoints per frame (>= nfeatures; the quadtree may return a
+ * few more than the quota per level, reference src/ORBextractor.cc:671-733). */
+int orbx_max_keypoints(const orbx_handle* h);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors)
+ * (reference src/ORBextractor.cc:1052-1114).  The mask is ignored by the
+ * reference (include/ORBextractor.h:45) and has no parameter here.
+ * img: 8-bit single channel, `stride` bytes per row, host memory.
+ * kps[cap], desc[cap*32]: host memory.  An empty image (w or h == 0) returns
+ * ORBX_OK with *n_out = 0, as the reference returns silently. */
+int orbx_extract(orbx_handle* h, const uint8_t* img, int w, int h_, size_t stride,
+                 orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Batched form: B frames of equal size.  Frame f starts at imgs + f*img_stride.
+ * Outputs for frame f start at kps + f*cap_per_frame and desc + f*cap_per_frame*32;
+ * n_out[f] receives its keypoint count.  mem_space applies to imgs, kps, desc
+ * and n_out alike.  With ORBX_MEM_DEVICE the call only enqueues work on the
+ * handle's stream. */
+int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int h_,
+                       size_t row_stride, size_t img_stride, orbx_keypoint* kps, uint8_t* desc,
+                       int cap_per_frame, int* n_out, int mem_space);
+
+/* mvImagePyramid[level] of frame `frame` of the last extract call (public
+ * member read by Frame::ComputeStereoMatches, reference src/Frame.cc:610,700).
+ * *ptr is DEVICE memory owned by the handle (level 0 aliases the caller's
+ * image when it was passed as device memory), valid until the next call. */
+int orbx_get_level(orbx_handle* h, int frame, int level, const uint8_t** ptr, int* w, int* h_,
+                   size_t* stride);
+
+/* Getters (reference include/ORBextractor.h:51-71).  Arrays have nlevels entries. */
+int orbx_levels(const orbx_handle* h);
+float orbx_scale_factor(const orbx_handle* h);
+const float* orbx_scale_factors(const orbx_handle* h);
+const float* orbx_inv_scale_factors(const orbx_handle* h);
+const float* orbx_level_sigma2(const orbx_handle* h);
+const float* orbx_inv_level_sigma2(const orbx_handle* h);
+const int32_t* orbx_features_per_level(const orbx_handle* h);
+
+/* ---- stage timing (HIP events on the handle's stream) ---- */
+enum {
+    ORBX_STAGE_PYRAMID = 0,
+    ORBX_STAGE_FAST = 1,
+    ORBX_STAGE_QUADTREE = 2,
+    ORBX_STAGE_BLUR = 3,
+    ORBX_STAGE_DESCRIBE = 4,
+    ORBX_STAGE_COUNT = 5
+};
+int orbx_profile_enable(orbx_handle* h, int on);
+/* Synchronises, then returns accumulated milliseconds and launch counts per
+ * stage since the last reset. */
+int orbx_profile_read(orbx_handle* h, float* ms, int* launches, int n);
+int orbx_profile_reset(orbx_handle* h);
+
+/* ---- debug taps used by the parity tests (stage outputs of the last pass) ---- */
+/* Pyramid level image of frame `frame`: copies w*h bytes, tightly packed, to host dst. */
+int orbx_debug_level(orbx_handle* h, int frame, int level, uint8_t* dst);
+/* Blurred level image of frame `frame`: copies w*h bytes, tightly packed, to host dst. */
+int orbx_debug_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, int* w, int* h_);
+/* FAST candidates of (frame, level) in the reference's append order; x,y relative
+ * to the detection origin (16,16).  Returns count via *n (may exceed cap). */
+int orbx_debug_candidates(orbx_handle* h, int frame, int level, int* xs, int* ys, int* resp,
+                          int cap, int* n);
+/* Quadtree selection of (frame, level): level-image pixel coordinates. */
+int orbx_debug_selected(orbx_handle* h, int frame, int level, int* xs, int* ys, int* resp, int cap,
+                        int* n);
+
+/* =====================  matching  ===================== */
+
+/* ORBmatcher::DescriptorDistance (reference src/ORBmatcher.cc:1905-1921). */
+int orbm_hamming256(const uint8_t* a, const uint8_t* b);
+
+#define ORBM_GRID_COLS 64 /* FRAME_GRID_COLS, reference include/Frame.h:26 */
+#define ORBM_GRID_ROWS 48 /* FRAME_GRID_ROWS, reference include/Frame.h:25 */
+
+typedef struct orbm_context orbm_context;
+
+/* A matcher context owns a stream and scratch on one device. */
+int orbm_create(int device, orbm_context** out);
+void orbm_destroy(orbm_context* m);
+int orbm_set_stream(orbm_context* m, void* hip_stream);
+int orbm_synchronize(orbm_context* m);
+
+/* One frame's matching inputs, all arrays in the memory space given to the call. */
+typedef struct orbm_frame {
+    const orbx_keypoint* kps; /* mvKeysUn */
+    const uint8_t* desc;      /* n x 32 */
+    int32_t n;
+    float min_x, min_y, max_x, max_y; /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+} orbm_frame;
+
+/* Frame::AssignFeaturesToGrid + PosInGrid (reference src/Frame.cc:302-317,
+ * 494-502).  CSR over 64x48 cells, cell id = ix*48 + iy; cell_start has
+ * 64*48+1 entries, cell_items up to n entries in ascending keypoint index. */
+int orbm_grid_build(orbm_context* m, const orbm_frame* f, int32_t* cell_start, int32_t* cell_items,
+                    int mem_space);
+
+/* Frame::GetFeaturesInArea for many queries (reference src/Frame.cc:437-490):
+ * query q = (x, y, r, min_level, max_level).  Emits, per query, the candidate
+ * indices in the reference's order (ix outer, iy inner, bucket order) and
+ * their Hamming distance to qdesc[q] when qdesc != NULL.  Fixed row capacity
+ * max_cand; counts[q] holds the true count (may exceed max_cand). */
+int orbm_window_candidates(orbm_context* m, const orbm_frame* train, const float* qx,
+                           const float* qy, const float* qr, const int32_t* qmin_level,
+                           const int32_t* qmax_level, const uint8_t* qdesc, int nq, int max_cand,
+                           int32_t* cand_idx, int32_t* cand_dist, int32_t* counts, int mem_space);
+
+/* ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:501-628),
+ * including its sequential best-distance bookkeeping and match stealing.
+ * prev_matched_xy: n1 x 2 floats in/out (vbPrevMatched); matches12: n1 ints out.
+ * *nmatches receives the return value of the reference function. */
+int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const orbm_frame* f2,
+                                   float* prev_matched_xy, int32_t* matches12, int window_size,
+                                   float nn_ratio, int check_orientation, int* nmatches,
+                                   int mem_space);
+
+/* ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono)
+ * (reference src/ORBmatcher.cc:1533-1678) from the point where each last-frame
+ * map point has been projected into the current frame (:1577-1578): the
+ * caller passes, per last-frame keypoint i, valid[i] (map point present and
+ * not an outlier, :1564-1566), the projection u[i], v[i], inverse depth
+ * invz[i], and has_obs[i] (pMP->Observations() > 0).  direction: 0 neither,
+ * 1 forward, 2 backward (:1554-1556).  scale_factors: mvScaleFactors.
+ * cur_claimed (in/out, n_cur ints): -1 = mvpMapPoints[i2] is NULL, else the
+ * index of the last-frame point assigned; cur_claimed_obs (in/out): whether
+ * that assigned point has observations (:1610-1612). */
+int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm_frame* last,
+                              const uint8_t* valid, const float* u, const float* v,
+                              const float* invz, const uint8_t* has_obs, const float* cur_u_right,
+                              const float* scale_factors, int nlevels, float bf, float th,
+                              int direction, int check_orientation, int32_t* cur_claimed,
+                              uint8_t* cur_claimed_obs, int* nmatches, int mem_space);
+
+/* Brute-force 2-nearest-neighbour search over 256-bit descriptors with the
+ * serial-scan semantics of the reference's descriptor loops
+ * (src/ORBmatcher.cc:255-282): best = smallest distance, lowest train index on
+ * ties; second = second smallest counting duplicates of the minimum; both start
+ * at 256.  train_index_base is added to best_idx (for sharded train sets). */
+int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
+              int train_index_base, int32_t* best_idx, int32_t* best_d, int32_t* second_d,
+              int mem_space);
+
+/* Merge two partial kNN-2 results for the same queries (shard A precedes shard
+ * B in global train order): reproduces the serial scan over A then B. */
+int orbm_knn2_merge(orbm_context* m, int nq, int32_t* best_idx_a, int32_t* best_d_a,
+                    int32_t* second_d_a, const int32_t* best_idx_b, const int32_t* best_d_b,
+                    const int32_t* second_d_b, int mem_space);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -1,0 +1,258 @@
+"""ctypes access to the CPU parity checker (oracle/liborb_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+bench.py's cpu_baseline leg.  The product package (slam_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liborb_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("blur_variant", C.c_int)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float),
+                ("max_y", C.c_float), ("scale_factors", C.c_void_p), ("nlevels", C.c_int)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.oracle_fast_atan2.restype = C.c_float
+        _lib.oracle_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.oracle_ic_angle.restype = C.c_float
+        _lib.oracle_cv_round.argtypes = [C.c_double]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def params(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, blur_variant=0):
+    return Params(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant)
+
+
+def tables(p):
+    n = p.nlevels
+    sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+    q = np.zeros(n, np.int32)
+    um = np.zeros(16, np.int32)
+    lib().oracle_tables(C.byref(p), _p(sc), _p(inv), _p(s2), _p(is2), _p(q), _p(um))
+    return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, quotas=q, umax=um)
+
+
+def level_size(p, w, h, level):
+    lw, lh = C.c_int(), C.c_int()
+    lib().oracle_level_size(C.byref(p), w, h, level, C.byref(lw), C.byref(lh))
+    return lw.value, lh.value
+
+
+def cv_round(v):
+    return lib().oracle_cv_round(float(v))
+
+
+def fast_atan2(y, x):
+    return lib().oracle_fast_atan2(float(y), float(x))
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().oracle_resize_linear(_p(src), src.shape[1], src.shape[0], C.c_size_t(src.strides[0]),
+                               _p(dst), dw, dh, C.c_size_t(dw))
+    return dst
+
+
+def gaussian7(src, variant=0):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().oracle_gaussian7(_p(src), src.shape[1], src.shape[0], C.c_size_t(src.strides[0]),
+                           _p(dst), C.c_size_t(dst.strides[0]), variant)
+    return dst
+
+
+def fast9_nms(roi, threshold):
+    roi = np.ascontiguousarray(roi, np.uint8)
+    cap = roi.size
+    xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+    n = lib().oracle_fast9_nms(_p(roi), roi.shape[1], roi.shape[0], C.c_size_t(roi.strides[0]),
+                               threshold, _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def pyramid_level(p, img, level):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    lw, lh = level_size(p, w, h, level)
+    dst = np.zeros((lh, lw), np.uint8)
+    lib().oracle_pyramid_level(C.byref(p), _p(img), w, h, C.c_size_t(img.strides[0]), level, _p(dst))
+    return dst
+
+
+def detect_cells(lvl, ini_th=20, min_th=7):
+    lvl = np.ascontiguousarray(lvl, np.uint8)
+    cap = max(16, lvl.size // 4 + 1024)
+    xs, ys, rs = (np.zeros(cap, np.int32) for _ in range(3))
+    n = lib().oracle_detect_cells(_p(lvl), lvl.shape[1], lvl.shape[0], C.c_size_t(lvl.strides[0]),
+                                  ini_th, min_th, _p(xs), _p(ys), _p(rs), cap)
+    assert n <= cap
+    return xs[:n].copy(), ys[:n].copy(), rs[:n].copy()
+
+
+def distribute(xs, ys, rs, min_x, max_x, min_y, max_y, n_target):
+    xs = np.ascontiguousarray(xs, np.int32)
+    ys = np.ascontiguousarray(ys, np.int32)
+    rs = np.ascontiguousarray(rs, np.int32)
+    cap = len(xs) + 16
+    out = np.zeros(cap, np.int32)
+    n = lib().oracle_distribute(_p(xs), _p(ys), _p(rs), len(xs), min_x, max_x, min_y, max_y,
+                                n_target, _p(out), cap)
+    return out[:n].copy()
+
+
+def ic_angle(lvl, x, y):
+    lvl = np.ascontiguousarray(lvl, np.uint8)
+    return lib().oracle_ic_angle(_p(lvl), C.c_size_t(lvl.strides[0]), int(x), int(y))
+
+
+def descriptor(blurred, x, y, angle_deg):
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().oracle_descriptor(_p(blurred), C.c_size_t(blurred.strides[0]), int(x), int(y),
+                            C.c_float(angle_deg), _p(d))
+    return d
+
+
+def extract(p, img, cap=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = cap or p.nfeatures + 64
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int()
+    rc = lib().oracle_extract(C.byref(p), _p(img), w, h, C.c_size_t(img.strides[0]), _p(kps),
+                              _p(desc), cap, C.byref(n))
+    if rc:
+        raise RuntimeError("oracle_extract failed rc=%d" % rc)
+    return kps[:n.value].copy(), desc[:n.value].copy()
+
+
+def extract_batch(p, imgs, cap=None, threads=1):
+    imgs = np.ascontiguousarray(imgs, np.uint8)
+    b, h, w = imgs.shape
+    cap = cap or p.nfeatures + 64
+    kps = np.zeros((b, cap), KP_DTYPE)
+    desc = np.zeros((b, cap, 32), np.uint8)
+    n = np.zeros(b, np.int32)
+    rc = lib().oracle_extract_batch(C.byref(p), _p(imgs), b, w, h, C.c_size_t(imgs.strides[1]),
+                                    C.c_size_t(imgs.strides[0]), _p(kps), _p(desc), cap, _p(n),
+                                    threads)
+    if rc:
+        raise RuntimeError("oracle_extract_batch failed rc=%d" % rc)
+    return kps, desc, n
+
+
+# ---------------------------------------------------------------- matching
+class FrameData:
+    """Keeps the numpy buffers alive behind an oracle_frame struct."""
+
+    def __init__(self, kps, desc, bounds, scale_factors):
+        self.kps = np.ascontiguousarray(kps, KP_DTYPE)
+        self.desc = np.ascontiguousarray(desc, np.uint8)
+        self.sf = np.ascontiguousarray(scale_factors, np.float32)
+        self.bounds = tuple(float(b) for b in bounds)
+        self.c = Frame(self.kps.ctypes.data, self.desc.ctypes.data, len(self.kps), self.bounds[0],
+                       self.bounds[1], self.bounds[2], self.bounds[3], self.sf.ctypes.data,
+                       len(self.sf))
+
+    @property
+    def n(self):
+        return len(self.kps)
+
+
+def hamming256(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().oracle_hamming256(_p(a), _p(b))
+
+
+def grid_build(fr):
+    start = np.zeros(64 * 48 + 1, np.int32)
+    items = np.zeros(max(fr.n, 1), np.int32)
+    lib().oracle_grid_build(C.byref(fr.c), _p(start), _p(items))
+    return start, items[:start[-1]].copy()
+
+
+def features_in_area(fr, start, items, x, y, r, min_level=-1, max_level=-1):
+    out = np.zeros(max(fr.n, 1), np.int32)
+    items = np.ascontiguousarray(items, np.int32)
+    n = lib().oracle_features_in_area(C.byref(fr.c), _p(start), _p(items), C.c_float(x),
+                                      C.c_float(y), C.c_float(r), min_level, max_level, _p(out),
+                                      len(out))
+    return out[:n].copy()
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    lib().oracle_three_maxima(_p(sizes), len(sizes), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def search_for_initialization(f1, f2, prev_matched, window_size=100, nn_ratio=0.9, check_ori=True):
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.zeros(max(f1.n, 1), np.int32)
+    n = lib().oracle_search_for_initialization(C.byref(f1.c), C.byref(f2.c), _p(pm), _p(m12),
+                                               int(window_size), C.c_float(nn_ratio),
+                                               int(bool(check_ori)))
+    return n, m12[:f1.n].copy(), pm
+
+
+def search_by_projection_frames(cur, last, valid, u, v, invz, has_obs, u_right, bf, th, direction,
+                                check_ori=True, claimed=None, claimed_obs=None):
+    valid = np.ascontiguousarray(valid, np.uint8)
+    u = np.ascontiguousarray(u, np.float32)
+    v = np.ascontiguousarray(v, np.float32)
+    invz = np.ascontiguousarray(invz, np.float32)
+    has_obs = np.ascontiguousarray(has_obs, np.uint8)
+    u_right = np.ascontiguousarray(u_right, np.float32)
+    cl = np.full(max(cur.n, 1), -1, np.int32) if claimed is None else np.array(claimed, np.int32)
+    co = np.zeros(max(cur.n, 1), np.uint8) if claimed_obs is None else np.array(claimed_obs, np.uint8)
+    n = lib().oracle_search_by_projection_frames(
+        C.byref(cur.c), C.byref(last.c), _p(valid), _p(u), _p(v), _p(invz), _p(has_obs),
+        _p(u_right), C.c_float(bf), C.c_float(th), int(direction), C.c_float(0.9),
+        int(bool(check_ori)), _p(cl), _p(co))
+    return n, cl[:cur.n].copy(), co[:cur.n].copy()
+
+
+def knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    nq = len(q)
+    bi, bd, sd = (np.zeros(nq, np.int32) for _ in range(3))
+    lib().oracle_knn2(_p(q), nq, _p(t), len(t), _p(bi), _p(bd), _p(sd))
+    return bi, bd, sd

@@ -1,0 +1,105 @@
+"""Loader for the HIP library (slam_amd/liborbx.so) and its ctypes signatures.
+
+There is no CPU fallback: if the library is missing, or no MI355X-class HIP
+device is present, loading or handle creation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbx.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+MEM_HOST, MEM_DEVICE = 0, 1
+STAGES = ("pyramid", "fast", "quadtree", "blur", "describe")
+
+
+class OrbxError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("max_width", C.c_int32),
+                ("max_height", C.c_int32), ("max_batch", C.c_int32), ("device", C.c_int32),
+                ("blur_variant", C.c_int32)]
+
+
+class MFrame(C.Structure):
+    _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int32), ("min_x", C.c_float),
+                ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+# Every exported symbol of include/orbx.h: (restype, argtypes)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SIGNATURES = {
+    "orbx_last_error": (C.c_char_p, []),
+    "orbx_version": (C.c_char_p, []),
+    "orbx_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
+    "orbx_destroy": (None, [_vp]),
+    "orbx_set_stream": (_i, [_vp, _vp]),
+    "orbx_synchronize": (_i, [_vp]),
+    "orbx_max_keypoints": (_i, [_vp]),
+    "orbx_extract": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _i, C.POINTER(_i)]),
+    "orbx_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _vp, _i, _vp, _i]),
+    "orbx_get_level": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
+                            C.POINTER(_sz)]),
+    "orbx_levels": (_i, [_vp]),
+    "orbx_scale_factor": (_f, [_vp]),
+    "orbx_scale_factors": (C.POINTER(_f), [_vp]),
+    "orbx_inv_scale_factors": (C.POINTER(_f), [_vp]),
+    "orbx_level_sigma2": (C.POINTER(_f), [_vp]),
+    "orbx_inv_level_sigma2": (C.POINTER(_f), [_vp]),
+    "orbx_features_per_level": (C.POINTER(C.c_int32), [_vp]),
+    "orbx_profile_enable": (_i, [_vp, _i]),
+    "orbx_profile_read": (_i, [_vp, _vp, _vp, _i]),
+    "orbx_profile_reset": (_i, [_vp]),
+    "orbx_debug_level": (_i, [_vp, _i, _i, _vp]),
+    "orbx_debug_blurred": (_i, [_vp, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i)]),
+    "orbx_debug_candidates": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
+    "orbx_debug_selected": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_i)]),
+    "orbm_hamming256": (_i, [_vp, _vp]),
+    "orbm_create": (_i, [_i, C.POINTER(_vp)]),
+    "orbm_destroy": (None, [_vp]),
+    "orbm_set_stream": (_i, [_vp, _vp]),
+    "orbm_synchronize": (_i, [_vp]),
+    "orbm_grid_build": (_i, [_vp, C.POINTER(MFrame), _vp, _vp, _i]),
+    "orbm_window_candidates": (_i, [_vp, C.POINTER(MFrame), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                    _vp, _vp, _vp, _i]),
+    "orbm_search_for_initialization": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), _vp, _vp, _i,
+                                            _f, _i, C.POINTER(_i), _i]),
+    "orbm_search_by_projection": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), _vp, _vp, _vp,
+                                       _vp, _vp, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp,
+                                       C.POINTER(_i), _i]),
+    "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
+    "orbm_knn2_merge": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liborbx.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrbxError("HIP library %s not built: run `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported: no partial library
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().orbx_last_error()
+        raise OrbxError("orbx status %d: %s" % (rc, msg.decode() if msg else ""))

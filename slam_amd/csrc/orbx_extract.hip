@@ -1,0 +1,1470 @@
+// ORB extraction on MI355X (gfx950): pyramid, per-cell FAST-9/16 with threshold
+// fallback, quadtree distribution, intensity-centroid orientation, 7x7
+// Gaussian blur and steered BRIEF, batched over frames.
+//
+// Replaces ORB_SLAM2::ORBextractor (reference src/ORBextractor.cc).  All
+// integer stages are exact; float stages keep the reference's operation order
+// (this file must be compiled with -ffp-contract=off).
+//
+// Kernel map (one stream, no host round trip between stages):
+//   k_resize    level l from level l-1      (ComputePyramid, :1117-1145)
+//   k_fast      one wave per 30-px cell     (ComputeKeyPointsOctTree, :772-839)
+//   k_quadtree  one workgroup per (frame,level) (DistributeOctTree, :540-765)
+//   k_blur      all levels, LDS-tiled separable integer filter (:1094-1095)
+//   k_describe  one wave per keypoint: IC_Angle (:59-88) + rBRIEF (:92-131)
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/orbx_pattern_31.h"
+#include "orbx_internal.h"
+
+namespace {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef unsigned long long u64;
+typedef long long i64;
+
+const int EDGE_THRESHOLD = 19;  // reference src/ORBextractor.cc:53
+const int MIN_BORDER = EDGE_THRESHOLD - 3;
+const int MAX_CELL = 59;  // largest cell side: ceil(width / floor(width/30)) < 60
+const int MAX_ROOTS = 64;
+
+struct LevelGeom {
+    int w, h;
+    i64 pyrOff;   // bytes into the per-frame pyramid block (levels >= 1)
+    int pyrPitch;
+    i64 blurOff;  // bytes into the per-frame blurred block
+    int blurPitch;
+    int blurTileBase, blurTilesX, blurTiles;
+    // FAST cells
+    int nCols, nRows, wCell, hCell;
+    int cellBase, nCells, cellCap, slotBase;
+    // quadtree
+    int quota, nIni, lcap, selBase, keyBase;
+    float hX;
+    // output
+    float scale, kpSize;
+};
+
+struct Geom {
+    int nlevels, w, h;
+    int totalCells, totalSlots, totalSel, totalBlurTiles;
+    i64 pyrFrameBytes, blurFrameBytes;
+    LevelGeom lv[ORBX_MAX_LEVELS];
+};
+
+struct ImgRef {
+    const u8* base;
+    i64 frameStride;
+    int pitch;
+};
+
+__device__ __forceinline__ ImgRef level_image(const Geom& g, int l, ImgRef img0, const u8* pyr) {
+    if (l == 0) return img0;
+    ImgRef r;
+    r.base = pyr + g.lv[l].pyrOff;
+    r.frameStride = g.pyrFrameBytes;
+    r.pitch = g.lv[l].pyrPitch;
+    return r;
+}
+
+// ------------------------------------------------------------------ resize
+struct ResizeTap {
+    u16 i0, i1;  // source indices (already clamped)
+    short c0, c1;  // 11-bit fixed-point weights
+};
+
+// Bilinear 8-bit downscale, fixed point: horizontal sums with 11-bit weights,
+// vertical combine ((b*(t>>4))>>16 twice, +2, >>2).  4 destination pixels per
+// thread, one 32-bit store.
+__global__ __launch_bounds__(256) void k_resize(ImgRef src, u8* dst, int dPitch, i64 dFrame, int dw,
+                                                 int dh, const ResizeTap* __restrict__ xt,
+                                                 const ResizeTap* __restrict__ yt) {
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= dw || y >= dh) return;
+    const int f = blockIdx.z;
+    const ResizeTap ty = yt[y];
+    const u8* r0 = src.base + (i64)f * src.frameStride + (i64)ty.i0 * src.pitch;
+    const u8* r1 = src.base + (i64)f * src.frameStride + (i64)ty.i1 * src.pitch;
+    u32 out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x0 + k;
+        if (x < dw) {
+            const ResizeTap tx = xt[x];
+            const int t0 = r0[tx.i0] * tx.c0 + r0[tx.i1] * tx.c1;
+            const int t1 = r1[tx.i0] * tx.c0 + r1[tx.i1] * tx.c1;
+            const int v = ((((int)ty.c0 * (t0 >> 4)) >> 16) + (((int)ty.c1 * (t1 >> 4)) >> 16) + 2) >> 2;
+            out |= (u32)(v & 0xFF) << (8 * k);
+        }
+    }
+    *(u32*)(dst + (i64)f * dFrame + (i64)y * dPitch + x0) = out;
+}
+
+// ------------------------------------------------------------------ blur
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+#define BLUR_TW 128
+#define BLUR_TH 16
+
+// Separable 7-tap integer Gaussian with reflect-101 borders.  Row sums fit 16
+// bits (257*255 = 65535); output = sat_u8((sum + 32768) >> 16).
+__global__ __launch_bounds__(256) void k_blur(Geom g, ImgRef img0, const u8* __restrict__ pyr,
+                                               u8* __restrict__ blur, int k0, int k1, int k2, int k3) {
+    __shared__ u8 tin[BLUR_TH + 6][BLUR_TW + 8];
+    __shared__ u16 hs[BLUR_TH + 6][BLUR_TW];
+    const int f = blockIdx.y;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].blurTileBase) l++;
+    const LevelGeom& L = g.lv[l];
+    const int t = blockIdx.x - L.blurTileBase;
+    const int tx0 = (t % L.blurTilesX) * BLUR_TW, ty0 = (t / L.blurTilesX) * BLUR_TH;
+    const ImgRef im = level_image(g, l, img0, pyr);
+    const u8* src = im.base + (i64)f * im.frameStride;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (BLUR_TH + 6) * (BLUR_TW + 6); i += 256) {
+        const int ry = i / (BLUR_TW + 6), rx = i - ry * (BLUR_TW + 6);
+        const int sy = reflect101(min(ty0 + ry - 3, L.h + 2), L.h);
+        const int sx = reflect101(min(tx0 + rx - 3, L.w + 2), L.w);
+        tin[ry][rx] = src[(i64)sy * im.pitch + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BLUR_TH + 6) * BLUR_TW; i += 256) {
+        const int ry = i / BLUR_TW, rx = i - ry * BLUR_TW;
+        const u8* p = &tin[ry][rx];
+        const int s = k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3];
+        hs[ry][rx] = (u16)s;
+    }
+    __syncthreads();
+    u8* dst = blur + (i64)f * g.blurFrameBytes + L.blurOff;
+    for (int i = tid; i < BLUR_TH * (BLUR_TW / 4); i += 256) {
+        const int ry = i / (BLUR_TW / 4), rx = (i - ry * (BLUR_TW / 4)) * 4;
+        const int oy = ty0 + ry, ox = tx0 + rx;
+        if (oy >= L.h || ox >= L.w) continue;
+        u32 out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = rx + k;
+            const int s = k0 * ((int)hs[ry][x] + hs[ry + 6][x]) + k1 * ((int)hs[ry + 1][x] + hs[ry + 5][x]) +
+                          k2 * ((int)hs[ry + 2][x] + hs[ry + 4][x]) + k3 * (int)hs[ry + 3][x];
+            int v = (s + 32768) >> 16;
+            v = v > 255 ? 255 : v;
+            out |= (u32)v << (8 * k);
+        }
+        *(u32*)(dst + (i64)oy * L.blurPitch + ox) = out;
+    }
+}
+
+// ------------------------------------------------------------------ FAST
+#define ROI_MAX (MAX_CELL + 6)
+
+__device__ __forceinline__ int wave_excl_count(bool flag, int* total) {
+    const u64 m = __ballot(flag);
+    *total = __popcll(m);
+    const u32 lo = (u32)m, hi = (u32)(m >> 32);
+    return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+}
+
+// FAST-9/16 strength of a pixel: M = max over the 16 arcs of 9 contiguous ring
+// pixels of the arc minimum of (v - p) [darker] or (p - v) [brighter].  The
+// pixel is a corner for threshold t iff M > t, and its response is M - 1.
+__device__ __forceinline__ int fast_strength(const int* d) {
+    // d[k] = v - ring[k], k = 0..15
+    int mn3[16], mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    }
+    int dark = -256, bright_neg = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int mn9 = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
+        const int mx9 = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
+        dark = max(dark, mn9);
+        bright_neg = min(bright_neg, mx9);
+    }
+    return max(dark, -bright_neg);
+}
+
+// One wave per cell: ROI -> LDS, strength plane, NMS at iniTh, fallback to
+// minTh when nothing survives, survivors written in raster order to the
+// cell's slot range.
+__global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, const u8* __restrict__ pyr,
+                                              u32* __restrict__ cellCount, u32* __restrict__ slots,
+                                              int iniTh, int minTh) {
+    __shared__ u8 roi[ROI_MAX * ROI_MAX + 3];
+    __shared__ u8 plane[(MAX_CELL + 2) * (MAX_CELL + 2) + 2];
+    __shared__ u16 work[MAX_CELL * MAX_CELL];
+    const int f = blockIdx.y;
+    const int cell = blockIdx.x;
+    int l = 0;
+    while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellBase) l++;
+    const LevelGeom& L = g.lv[l];
+    const int c = cell - L.cellBase;
+    const int ci = c / L.nCols, cj = c - ci * L.nCols;
+    const int lane = threadIdx.x;
+    u32* cnt = cellCount + (i64)f * g.totalCells + cell;
+    const int maxBX = L.w - MIN_BORDER, maxBY = L.h - MIN_BORDER;
+    const int iniX = MIN_BORDER + cj * L.wCell, iniY = MIN_BORDER + ci * L.hCell;
+    const int rw = min(iniX + L.wCell + 6, maxBX) - iniX;
+    const int rh = min(iniY + L.hCell + 6, maxBY) - iniY;
+    if (rw < 7 || rh < 7) {
+        if (lane == 0) *cnt = 0;
+        return;
+    }
+    const ImgRef im = level_image(g, l, img0, pyr);
+    const u8* src = im.base + (i64)f * im.frameStride + (i64)iniY * im.pitch + iniX;
+    for (int i = lane; i < rw * rh; i += 64) {
+        const int y = i / rw, x = i - y * rw;
+        roi[i] = src[(i64)y * im.pitch + x];
+    }
+    const int iw = rw - 6, ih = rh - 6, pw = iw + 2;
+    for (int i = lane; i < pw * (ih + 2); i += 64) plane[i] = 0;
+    __syncthreads();
+
+    // Phase 1: cheap necessary test at the lower threshold on two opposite ring
+    // pairs per axis; survivors are queued for the full evaluation.
+    const int lowTh = min(iniTh, minTh);
+    int nwork = 0;
+    for (int base = 0; base < iw * ih; base += 64) {
+        const int i = base + lane;
+        bool pass = false;
+        if (i < iw * ih) {
+            const int y = i / iw, x = i - y * iw;
+            const u8* p = &roi[(y + 3) * rw + x + 3];
+            const int v = p[0];
+            const int d0 = v - p[3 * rw], d8 = v - p[-3 * rw], d4 = v - p[3], d12 = v - p[-3];
+            const bool dk = (d0 > lowTh || d8 > lowTh) && (d4 > lowTh || d12 > lowTh);
+            const bool br = (d0 < -lowTh || d8 < -lowTh) && (d4 < -lowTh || d12 < -lowTh);
+            pass = dk || br;
+        }
+        int tot;
+        const int off = wave_excl_count(pass, &tot);
+        if (pass) work[nwork + off] = (u16)i;
+        nwork += tot;
+    }
+    __syncthreads();
+    // Phase 2: full strength for queued pixels.
+    for (int base = 0; base < nwork; base += 64) {
+        const int wi = base + lane;
+        if (wi < nwork) {
+            const int i = work[wi];
+            const int y = i / iw, x = i - y * iw;
+            const u8* p = &roi[(y + 3) * rw + x + 3];
+            const int v = p[0];
+            int d[16];
+            d[0] = v - p[3 * rw];
+            d[1] = v - p[3 * rw + 1];
+            d[2] = v - p[2 * rw + 2];
+            d[3] = v - p[rw + 3];
+            d[4] = v - p[3];
+            d[5] = v - p[-rw + 3];
+            d[6] = v - p[-2 * rw + 2];
+            d[7] = v - p[-3 * rw + 1];
+            d[8] = v - p[-3 * rw];
+            d[9] = v - p[-3 * rw - 1];
+            d[10] = v - p[-2 * rw - 2];
+            d[11] = v - p[-rw - 3];
+            d[12] = v - p[-3];
+            d[13] = v - p[rw - 3];
+            d[14] = v - p[2 * rw - 2];
+            d[15] = v - p[3 * rw - 1];
+            const int m = fast_strength(d);
+            plane[(y + 1) * pw + x + 1] = (u8)max(m, 0);
+        }
+    }
+    __syncthreads();
+
+    u32* out = slots + (i64)f * g.totalSlots + L.slotBase + (i64)c * L.cellCap;
+    const int gx0 = cj * L.wCell + 3, gy0 = ci * L.hCell + 3;  // relative to the detection origin
+    int total = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        int th = pass == 0 ? iniTh : minTh;
+        th = min(max(th, 0), 255);
+        for (int base = 0; base < iw * ih; base += 64) {
+            const int i = base + lane;
+            bool keep = false;
+            int x = 0, y = 0, s = 0;
+            if (i < iw * ih) {
+                y = i / iw;
+                x = i - y * iw;
+                const u8* q = &plane[(y + 1) * pw + x + 1];
+                const int m = q[0];
+                if (m > th) {
+                    s = m - 1;
+#define SC(o) ((int)q[o] > th ? (int)q[o] - 1 : 0)
+                    keep = s > SC(-1) && s > SC(1) && s > SC(-pw - 1) && s > SC(-pw) &&
+                           s > SC(-pw + 1) && s > SC(pw - 1) && s > SC(pw) && s > SC(pw + 1);
+#undef SC
+                }
+            }
+            int tot;
+            const int off = wave_excl_count(keep, &tot);
+            if (keep && total + off < L.cellCap) out[total + off] = ORBX_PACK(gx0 + x, gy0 + y, s);
+            total += tot;
+        }
+        if (total > 0) break;
+    }
+    if (lane == 0) *cnt = (u32)min(total, L.cellCap);
+}
+
+// ------------------------------------------------------------------ quadtree
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan over the 256 threads of the block; *total = block sum.
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* wsum) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int inc = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int s = wsum[k];
+        if (k < wv) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+struct QtShared {
+    int n, L, prevL, tnew, ncut, nproc, toExpand, done, careful, C;
+    int wsum[4];
+};
+
+__device__ __forceinline__ int child_quadrant(u32 key, short4 b) {
+    // b = (x0, x1, y0, y1); split at x0 + ceil((x1-x0)/2), y0 + ceil((y1-y0)/2)
+    const int xm = b.x + ((b.y - b.x + 1) >> 1);
+    const int ym = b.z + ((b.w - b.z + 1) >> 1);
+    const int x = ORBX_PX(key), y = ORBX_PY(key);
+    return (x < xm ? 0 : 1) + (y < ym ? 0 : 2);
+}
+
+__device__ __forceinline__ short4 child_box(short4 b, int q) {
+    const short xm = (short)(b.x + ((b.y - b.x + 1) >> 1));
+    const short ym = (short)(b.z + ((b.w - b.z + 1) >> 1));
+    short4 r;
+    r.x = (q & 1) ? xm : b.x;
+    r.y = (q & 1) ? b.y : xm;
+    r.z = (q & 2) ? ym : b.z;
+    r.w = (q & 2) ? b.w : ym;
+    return r;
+}
+
+// DistributeOctTree for one (frame, level).  The list of nodes is kept as
+// arrays indexed by list position; every pass rebuilds the list with prefix
+// sums so that positions, creation order and the stop rule equal those of the
+// sequential algorithm.  Node "addresses" in the size sort are modelled by
+// creation order (later created = greater).
+__global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict__ cellCount,
+                                                   const u32* __restrict__ slots, u32* keyPacked,
+                                                   u16* keyNode, u32* sel, int* selCount,
+                                                   int* errFlag) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ QtShared S;
+    const int l = blockIdx.x, f = blockIdx.y;
+    const LevelGeom& LG = g.lv[l];
+    const int tid = threadIdx.x;
+    const int lcap = LG.lcap;
+    const int N = LG.quota;
+    int* selCnt = selCount + (i64)f * ORBX_MAX_LEVELS + l;
+    u32* selOut = sel + (i64)f * g.totalSel + LG.selBase;
+
+    // LDS carve-up (all arrays have lcap entries unless noted)
+    short4* box[2];
+    u32* cnt[2];
+    u32* seq[2];
+    unsigned char* p = smem;
+    box[0] = (short4*)p; p += (size_t)lcap * 8;
+    box[1] = (short4*)p; p += (size_t)lcap * 8;
+    u32* childCnt = (u32*)p; p += (size_t)lcap * 16;  // 4 per node; reused as u64 best[]
+    cnt[0] = (u32*)p; p += (size_t)lcap * 4;
+    cnt[1] = (u32*)p; p += (size_t)lcap * 4;
+    seq[0] = (u32*)p; p += (size_t)lcap * 4;
+    seq[1] = (u32*)p; p += (size_t)lcap * 4;
+    u32* gpre = (u32*)p; p += (size_t)lcap * 4;     // by rank: exclusive prefix of children
+    u16* newId = (u16*)p; p += (size_t)lcap * 8;    // 4 per node: list position of each child
+    u16* moved = (u16*)p; p += (size_t)lcap * 2;    // new position of a node that stays
+    u16* rankOf = (u16*)p; p += (size_t)lcap * 2;   // processing rank of a node (0xFFFF: none)
+    u16* nodeOfRank = (u16*)p; p += (size_t)lcap * 2;
+    u8* mOf = (u8*)p; p += (size_t)lcap;            // non-empty children of a node
+
+    // ---- gather the level's candidates into a dense array (reference order:
+    // cell row-major, raster inside a cell)
+    const u32* cc = cellCount + (i64)f * g.totalCells + LG.cellBase;
+    const u32* sl = slots + (i64)f * g.totalSlots + LG.slotBase;
+    u32* kp = keyPacked + (i64)f * g.totalSlots + LG.slotBase;
+    u16* kn = keyNode + (i64)f * g.totalSlots + LG.slotBase;
+    int nkeys = 0;
+    for (int base = 0; base < LG.nCells; base += 256) {
+        const int c = base + tid;
+        const int cN = c < LG.nCells ? (int)cc[c] : 0;
+        int tot;
+        const int off = block_excl_scan(cN, &tot, S.wsum);
+        for (int k = 0; k < cN; k++) kp[nkeys + off + k] = sl[(i64)c * LG.cellCap + k];
+        nkeys += tot;
+    }
+    __syncthreads();
+    if (nkeys == 0) {
+        if (tid == 0) *selCnt = 0;
+        return;
+    }
+
+    // ---- roots (reference :545-587)
+    const int nIni = LG.nIni;
+    const float hX = LG.hX;
+    const int ySpan = LG.h - 2 * MIN_BORDER;
+    for (int i = tid; i < lcap; i += 256) cnt[0][i] = 0;
+    __syncthreads();
+    for (int k = tid; k < nkeys; k += 256) {
+        const int r = (int)((float)ORBX_PX(kp[k]) / hX);
+        kn[k] = (u16)r;
+        atomicAdd(&cnt[0][r], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // compact non-empty roots, keeping order; moved[r] = list position
+        int L = 0;
+        for (int r = 0; r < nIni; r++) {
+            const u32 c = cnt[0][r];
+            if (c > 0) {
+                moved[r] = (u16)L;
+                short4 b;
+                b.x = (short)(int)(hX * (float)r);
+                b.y = (short)(int)(hX * (float)(r + 1));
+                b.z = 0;
+                b.w = (short)ySpan;
+                box[1][L] = b;
+                cnt[1][L] = c;
+                seq[1][L] = (u32)r;
+                L++;
+            }
+        }
+        S.L = L;
+        S.careful = 0;
+        S.done = 0;
+    }
+    __syncthreads();
+    for (int k = tid; k < nkeys; k += 256) kn[k] = moved[kn[k]];
+    int cur = 1;  // buffer holding the current list
+    u32 nextSeq = (u32)nIni;
+    __syncthreads();
+
+    // ---- subdivision passes (reference :596-741)
+    for (int iter = 0; iter < 64; iter++) {
+        const int L = S.L;
+        const int careful = S.careful;
+        const short4* cb = box[cur];
+        const u32* ccnt = cnt[cur];
+        const u32* cseq = seq[cur];
+        const int nxt = cur ^ 1;
+        for (int i = tid; i < L * 4; i += 256) childCnt[i] = 0;
+        __syncthreads();
+        for (int k = tid; k < nkeys; k += 256) {
+            const int nd = kn[k];
+            if (ccnt[nd] > 1) atomicAdd(&childCnt[nd * 4 + child_quadrant(kp[k], cb[nd])], 1u);
+        }
+        __syncthreads();
+        // processing order of expandable nodes
+        int C = 0;
+        if (!careful) {
+            for (int base = 0; base < L; base += 256) {
+                const int i = base + tid;
+                const int e = (i < L && ccnt[i] > 1) ? 1 : 0;
+                int tot;
+                const int off = block_excl_scan(e, &tot, S.wsum);
+                if (i < L) rankOf[i] = e ? (u16)(C + off) : (u16)0xFFFF;
+                C += tot;
+            }
+        } else {
+            // rank by (count desc, creation order desc)
+            for (int i = tid; i < L; i += 256) {
+                const u32 ci = ccnt[i];
+                u16 r = 0xFFFF;
+                if (ci > 1) {
+                    const u64 ki = ((u64)ci << 32) | cseq[i];
+                    int rk = 0;
+                    for (int j = 0; j < L; j++) {
+                        const u32 cj = ccnt[j];
+                        if (cj > 1 && (((u64)cj << 32) | cseq[j]) > ki) rk++;
+                    }
+                    r = (u16)rk;
+                }
+                rankOf[i] = r;
+            }
+            for (int base = 0; base < L; base += 256) {
+                const int i = base + tid;
+                const int e = (i < L && ccnt[i] > 1) ? 1 : 0;
+                int tot;
+                block_excl_scan(e, &tot, S.wsum);
+                C += tot;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < L; i += 256) {
+            const u16 r = rankOf[i];
+            int m = 0;
+            if (r != 0xFFFF) {
+                nodeOfRank[r] = (u16)i;
+                m = (childCnt[i * 4] > 0) + (childCnt[i * 4 + 1] > 0) + (childCnt[i * 4 + 2] > 0) +
+                    (childCnt[i * 4 + 3] > 0);
+            }
+            mOf[i] = (u8)m;
+        }
+        __syncthreads();
+        // scan over ranks: children created before rank j, and the cut
+        int run = 0, below = 0;
+        for (int base = 0; base < C; base += 256) {
+            const int j = base + tid;
+            const int m = j < C ? (int)mOf[nodeOfRank[j]] : 0;
+            int tot;
+            const int off = block_excl_scan(m, &tot, S.wsum);
+            int lt = 0;
+            if (j < C) {
+                gpre[j] = (u32)(run + off);
+                // list size after processing ranks 0..j (each split removes the parent)
+                lt = (L + (run + off + m) - (j + 1)) < N ? 1 : 0;
+            }
+            int tl;
+            block_excl_scan(lt, &tl, S.wsum);
+            below += tl;
+            run += tot;
+        }
+        int nproc = C;
+        if (careful) nproc = min(C, below + 1);
+        __syncthreads();
+        int tnew = 0;
+        if (nproc > 0) {
+            const int last = nodeOfRank[nproc - 1];
+            tnew = (int)gpre[nproc - 1] + (int)mOf[last];
+        }
+        // nodes that stay: new position = tnew + rank among stayers in list order
+        int stay = 0;
+        for (int base = 0; base < L; base += 256) {
+            const int i = base + tid;
+            const int s = (i < L && (rankOf[i] == 0xFFFF || rankOf[i] >= nproc)) ? 1 : 0;
+            int tot;
+            const int off = block_excl_scan(s, &tot, S.wsum);
+            if (s) {
+                const int np = tnew + stay + off;
+                moved[i] = (u16)np;
+                if (np < lcap) {
+                    box[nxt][np] = cb[i];
+                    cnt[nxt][np] = ccnt[i];
+                    seq[nxt][np] = cseq[i];
+                }
+            }
+            stay += tot;
+        }
+        // children of processed nodes, pushed to the front in processing order
+        int expand = 0;
+        for (int i = tid; i < L; i += 256) {
+            const u16 r = rankOf[i];
+            if (r != 0xFFFF && r < nproc) {
+                int gidx = (int)gpre[r];
+                for (int q = 0; q < 4; q++) {
+                    const u32 c = childCnt[i * 4 + q];
+                    if (c > 0) {
+                        const int np = tnew - 1 - gidx;
+                        newId[i * 4 + q] = (u16)np;
+                        if (np < lcap) {
+                            box[nxt][np] = child_box(cb[i], q);
+                            cnt[nxt][np] = c;
+                            seq[nxt][np] = nextSeq + (u32)gidx;
+                        }
+                        if (c > 1) expand++;
+                        gidx++;
+                    }
+                }
+            }
+        }
+        {
+            int tot;
+            block_excl_scan(expand, &tot, S.wsum);
+            expand = tot;
+        }
+        __syncthreads();
+        for (int k = tid; k < nkeys; k += 256) {
+            const int nd = kn[k];
+            const u16 r = rankOf[nd];
+            if (r != 0xFFFF && r < nproc)
+                kn[k] = newId[nd * 4 + child_quadrant(kp[k], cb[nd])];
+            else
+                kn[k] = moved[nd];
+        }
+        nextSeq += (u32)tnew;
+        const int newL = tnew + stay;
+        __syncthreads();
+        if (tid == 0) {
+            if (newL > lcap) {
+                *errFlag = 1;
+                S.done = 1;
+            }
+            S.L = min(newL, lcap);
+            if (newL >= N || newL == L)
+                S.done = 1;
+            else if (!careful && newL + 3 * expand > N)
+                S.careful = 1;
+        }
+        cur = nxt;
+        __syncthreads();
+        if (S.done) break;
+    }
+
+    // ---- best key per node: max response, first in candidate order on ties
+    const int L = S.L;
+    u64* best = (u64*)childCnt;
+    for (int i = tid; i < L; i += 256) best[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < nkeys; k += 256) {
+        const u64 v = ((u64)ORBX_PR(kp[k]) << 32) | (u64)(0xFFFFFFFFu - (u32)k);
+        atomicMax(&best[kn[k]], v);
+    }
+    __syncthreads();
+    for (int i = tid; i < L; i += 256) {
+        const u32 k = 0xFFFFFFFFu - (u32)(best[i] & 0xFFFFFFFFu);
+        const u32 key = kp[k];
+        selOut[i] = ORBX_PACK(ORBX_PX(key) + MIN_BORDER, ORBX_PY(key) + MIN_BORDER, ORBX_PR(key));
+    }
+    if (tid == 0) *selCnt = L;
+}
+
+// ------------------------------------------------------------------ describe
+__constant__ signed char c_pattern[ORBX_PATTERN_POINTS * 2];
+__constant__ signed char c_patch_uv[749 * 2];  // (u, v) of the circular patch, radius 15
+
+// cv::fastAtan2 restated: degrees in [0, 360), one rounding per operation.
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+    const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+    const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    const float eps = 2.2204460492503131e-16f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// Float sine/cosine of the descriptor steering angle.  Evaluated in double
+// precision and rounded once to float.
+__device__ __forceinline__ void steer_sincos(float angle, float* s, float* c) {
+    *s = (float)sin((double)angle);
+    *c = (float)cos((double)angle);
+}
+
+// One wave per output keypoint slot: orientation on the level image, 256
+// steered tests on the blurred level, 28-byte keypoint + 32-byte descriptor.
+__global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8* __restrict__ pyr,
+                                                   const u8* __restrict__ blur,
+                                                   const u32* __restrict__ sel,
+                                                   const int* __restrict__ selCount,
+                                                   orbx_keypoint* kps, u8* desc, int cap, int* nOut,
+                                                   int* errFlag) {
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int* sc = selCount + (i64)f * ORBX_MAX_LEVELS;
+    int l = -1, idx = 0, total = 0;
+    for (int k = 0; k < g.nlevels; k++) {
+        const int c = sc[k];
+        if (l < 0 && s < total + c) {
+            l = k;
+            idx = s - total;
+        }
+        total += c;
+    }
+    if (s == 0 && lane == 0) {
+        nOut[f] = min(total, cap);
+        if (total > cap) *errFlag = 2;
+    }
+    if (l < 0 || s >= cap) return;
+    const LevelGeom& L = g.lv[l];
+    const u32 key = sel[(i64)f * g.totalSel + L.selBase + idx];
+    const int x = ORBX_PX(key), y = ORBX_PY(key);
+
+    const ImgRef im = level_image(g, l, img0, pyr);
+    const u8* center = im.base + (i64)f * im.frameStride + (i64)y * im.pitch + x;
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 749; i += 64) {
+        const int u = c_patch_uv[2 * i], v = c_patch_uv[2 * i + 1];
+        const int val = center[(i64)v * im.pitch + u];
+        m10 += u * val;
+        m01 += v * val;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    const float factorPI = (float)(M_PI / 180.f);
+    float a, b;
+    steer_sincos(__fmul_rn(angle, factorPI), &b, &a);
+    const u8* bc = blur + (i64)f * g.blurFrameBytes + L.blurOff + (i64)y * L.blurPitch + x;
+    u64 bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int t = r * 64 + lane;
+        const float x0 = (float)c_pattern[4 * t], y0 = (float)c_pattern[4 * t + 1];
+        const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = bc[(i64)r0 * L.blurPitch + c0];
+        const int t1 = bc[(i64)r1 * L.blurPitch + c1];
+        bits[r] = __ballot(t0 < t1);
+    }
+    const i64 o = (i64)f * cap + s;
+    if (lane < 4) {
+        const u64 v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        u32* d = (u32*)(desc + o * 32 + lane * 8);
+        d[0] = (u32)v;
+        d[1] = (u32)(v >> 32);
+    }
+    if (lane == 0) {
+        orbx_keypoint k;
+        k.x = (float)x;
+        k.y = (float)y;
+        if (l != 0) {
+            k.x = __fmul_rn(k.x, L.scale);
+            k.y = __fmul_rn(k.y, L.scale);
+        }
+        k.size = L.kpSize;
+        k.angle = angle;
+        k.response = (float)ORBX_PR(key);
+        k.octave = l;
+        k.class_id = -1;
+        kps[o] = k;
+    }
+}
+
+// ------------------------------------------------------------------ host
+int cv_round_host(double v) { return (int)lrint(v); }
+
+struct StageProfile {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[ORBX_STAGE_COUNT];
+    size_t used[ORBX_STAGE_COUNT] = {0, 0, 0, 0, 0};
+    double ms[ORBX_STAGE_COUNT] = {0, 0, 0, 0, 0};
+    int launches[ORBX_STAGE_COUNT] = {0, 0, 0, 0, 0};
+};
+
+}  // namespace
+
+struct orbx_handle {
+    orbx_config cfg;
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    // constructor tables
+    float scale[ORBX_MAX_LEVELS], invScale[ORBX_MAX_LEVELS], sigma2[ORBX_MAX_LEVELS],
+        invSigma2[ORBX_MAX_LEVELS];
+    int32_t quota[ORBX_MAX_LEVELS];
+    int gaussK[4];
+    // geometry of the current image size
+    Geom g;
+    bool geomValid = false;
+    size_t qtLds = 0;
+    ResizeTap* dTaps = nullptr;  // x taps then y taps for each level >= 1
+    size_t tapsCap = 0;
+    size_t tapXOff[ORBX_MAX_LEVELS], tapYOff[ORBX_MAX_LEVELS];
+    // scratch sized for scratchBatch frames of the current geometry
+    int scratchBatch = 0;
+    size_t scratchSig = 0;
+    u8 *dPyr = nullptr, *dBlur = nullptr;
+    u32 *dCellCount = nullptr, *dSlots = nullptr, *dKeyPacked = nullptr, *dSel = nullptr;
+    u16* dKeyNode = nullptr;
+    int *dSelCount = nullptr, *dErr = nullptr;
+    // staging for host-memory calls
+    u8* dImgStage = nullptr;
+    size_t imgStageCap = 0;
+    orbx_keypoint* dKpStage = nullptr;
+    u8* dDescStage = nullptr;
+    int* dNStage = nullptr;
+    size_t outStageCap = 0;
+    // last call (for orbx_get_level and the debug taps)
+    ImgRef lastImg0 = {nullptr, 0, 0};
+    int lastBatch = 0, lastFirstFrame = 0;
+    bool profiling = false;
+    StageProfile prof;
+};
+
+namespace {
+
+void free_dev(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+void make_tables(orbx_handle* h) {
+    // reference src/ORBextractor.cc:404-440; scaleFactor is stored as a double
+    const int n = h->cfg.nlevels;
+    const double sf = (double)h->cfg.scale_factor;
+    h->scale[0] = 1.0f;
+    h->sigma2[0] = 1.0f;
+    for (int i = 1; i < n; i++) {
+        h->scale[i] = (float)(h->scale[i - 1] * sf);
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    for (int i = 0; i < n; i++) {
+        h->invScale[i] = 1.0f / h->scale[i];
+        h->invSigma2[i] = 1.0f / h->sigma2[i];
+    }
+    float factor = (float)(1.0f / sf);
+    float desired = h->cfg.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)n));
+    int sum = 0;
+    for (int level = 0; level < n - 1; level++) {
+        h->quota[level] = cv_round_host(desired);
+        sum += h->quota[level];
+        desired *= factor;
+    }
+    h->quota[n - 1] = std::max(h->cfg.nfeatures - sum, 0);
+    if (h->cfg.blur_variant == 1) {
+        h->gaussK[0] = 18; h->gaussK[1] = 34; h->gaussK[2] = 48; h->gaussK[3] = 56;
+    } else {
+        h->gaussK[0] = 18; h->gaussK[1] = 34; h->gaussK[2] = 49; h->gaussK[3] = 55;
+    }
+}
+
+int upload_constants() {
+    // circular patch of radius 15 (reference src/ORBextractor.cc:450-465: umax)
+    static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    signed char uv[749 * 2];
+    int n = 0;
+    for (int v = -15; v <= 15; v++) {
+        const int d = umax[v < 0 ? -v : v];
+        for (int u = -d; u <= d; u++) {
+            uv[2 * n] = (signed char)u;
+            uv[2 * n + 1] = (signed char)v;
+            n++;
+        }
+    }
+    if (n != 749) {
+        orbx_set_error("internal: patch has %d pixels", n);
+        return ORBX_ERR_INVALID;
+    }
+    ORBX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_patch_uv), uv, sizeof(uv)));
+    ORBX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ORBX_PATTERN_31, sizeof(ORBX_PATTERN_31)));
+    return ORBX_OK;
+}
+
+int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// Level sizes, cell grids, quadtree parameters and scratch offsets for a w x h image.
+int compute_geometry(orbx_handle* h, int w, int hh) {
+    Geom& g = h->g;
+    if (h->geomValid && g.w == w && g.h == hh) return ORBX_OK;
+    memset(&g, 0, sizeof(g));
+    g.nlevels = h->cfg.nlevels;
+    g.w = w;
+    g.h = hh;
+    i64 pyrOff = 0, blurOff = 0;
+    int cellBase = 0, slotBase = 0, selBase = 0, tileBase = 0;
+    size_t maxLds = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        // reference src/ORBextractor.cc:1121-1122
+        L.w = cv_round_host((float)w * h->invScale[l]);
+        L.h = cv_round_host((float)hh * h->invScale[l]);
+        if (L.w < 1 || L.h < 1 || L.w > 4096 || L.h > 4096) {
+            orbx_set_error("level %d size %dx%d outside [1,4096]", l, L.w, L.h);
+            return ORBX_ERR_UNSUPPORTED;
+        }
+        L.pyrPitch = align_up(L.w, 64);
+        L.blurPitch = align_up(L.w, 64);
+        if (l > 0) {
+            L.pyrOff = pyrOff;
+            pyrOff += (i64)L.pyrPitch * L.h;
+        }
+        L.blurOff = blurOff;
+        blurOff += (i64)L.blurPitch * L.h;
+        L.blurTilesX = (L.w + BLUR_TW - 1) / BLUR_TW;
+        L.blurTiles = L.blurTilesX * ((L.h + BLUR_TH - 1) / BLUR_TH);
+        L.blurTileBase = tileBase;
+        tileBase += L.blurTiles;
+        // reference src/ORBextractor.cc:781-797
+        const float width = (float)((L.w - MIN_BORDER) - MIN_BORDER);
+        const float height = (float)((L.h - MIN_BORDER) - MIN_BORDER);
+        L.nCols = (int)(width / 30.f);
+        L.nRows = (int)(height / 30.f);
+        if (L.nCols <= 0 || L.nRows <= 0) {
+            L.nCols = L.nRows = 0;
+            L.wCell = L.hCell = 1;
+        } else {
+            L.wCell = (int)ceilf(width / L.nCols);
+            L.hCell = (int)ceilf(height / L.nRows);
+        }
+        if (L.wCell > MAX_CELL || L.hCell > MAX_CELL) {
+            orbx_set_error("internal: cell %dx%d too large", L.wCell, L.hCell);
+            return ORBX_ERR_UNSUPPORTED;
+        }
+        L.nCells = L.nCols * L.nRows;
+        L.cellBase = cellBase;
+        cellBase += L.nCells;
+        // no two survivors of 8-neighbour non-max suppression are adjacent
+        L.cellCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+        L.slotBase = slotBase;
+        L.keyBase = slotBase;
+        slotBase += L.nCells * L.cellCap;
+        // reference src/ORBextractor.cc:545-547
+        L.quota = h->quota[l];
+        L.nIni = 0;
+        L.hX = 1.f;
+        if (L.nCells > 0) {
+            const int dx = L.w - 2 * MIN_BORDER, dy = L.h - 2 * MIN_BORDER;
+            L.nIni = (int)roundf((float)dx / (float)dy);
+            if (L.nIni < 1 || L.nIni > MAX_ROOTS) {
+                orbx_set_error("level %d aspect ratio %d:%d unsupported (initial nodes %d)", l, dx, dy, L.nIni);
+                return ORBX_ERR_UNSUPPORTED;
+            }
+            L.hX = (float)dx / (float)L.nIni;
+        }
+        L.lcap = align_up(std::max(std::max(L.quota, 4 * L.nIni), MAX_ROOTS) + 8, 8);
+        if (L.lcap > 60000) {
+            orbx_set_error("nfeatures too large (%d at level %d)", L.quota, l);
+            return ORBX_ERR_UNSUPPORTED;
+        }
+        L.selBase = selBase;
+        selBase += L.lcap;
+        maxLds = std::max(maxLds, (size_t)L.lcap * 72 + 128);
+        L.scale = h->scale[l];
+        L.kpSize = (float)(int)(31 * h->scale[l]);  // reference :847, :857
+    }
+    g.totalCells = std::max(cellBase, 1);
+    g.totalSlots = std::max(slotBase, 1);
+    g.totalSel = selBase;
+    g.totalBlurTiles = tileBase;
+    g.pyrFrameBytes = align_up((int)std::max<i64>(pyrOff, 64), 256);
+    g.blurFrameBytes = align_up((int)blurOff, 256);
+    if (maxLds > 160 * 1024 - 1024) {
+        orbx_set_error("nfeatures too large for the quadtree's LDS budget (%zu bytes)", maxLds);
+        return ORBX_ERR_UNSUPPORTED;
+    }
+    h->qtLds = maxLds;
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)maxLds));
+
+    // resize taps (cv::resize INTER_LINEAR, 8-bit, 11-bit fixed-point weights)
+    std::vector<ResizeTap> taps;
+    for (int l = 1; l < g.nlevels; l++) {
+        const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
+        const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+        h->tapXOff[l] = taps.size();
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= sx;
+            if (sx < 0) {
+                fx = 0;
+                sx = 0;
+            }
+            if (sx >= sw - 1) {
+                fx = 0;
+                sx = sw - 1;
+            }
+            ResizeTap t;
+            t.i0 = (u16)sx;
+            t.i1 = (u16)std::min(sx + 1, sw - 1);
+            t.c0 = (short)cv_round_host((1.f - fx) * 2048);
+            t.c1 = (short)cv_round_host(fx * 2048);
+            taps.push_back(t);
+        }
+        h->tapYOff[l] = taps.size();
+        for (int dy = 0; dy < dh; dy++) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = (int)floorf(fy);
+            fy -= sy;
+            ResizeTap t;
+            t.i0 = (u16)std::min(std::max(sy, 0), sh - 1);
+            t.i1 = (u16)std::min(std::max(sy + 1, 0), sh - 1);
+            t.c0 = (short)cv_round_host((1.f - fy) * 2048);
+            t.c1 = (short)cv_round_host(fy * 2048);
+            taps.push_back(t);
+        }
+    }
+    if (taps.size() > h->tapsCap) {
+        free_dev(h->dTaps);
+        h->dTaps = nullptr;
+        h->tapsCap = 0;
+        ORBX_HIP_CHECK(hipMalloc((void**)&h->dTaps, taps.size() * sizeof(ResizeTap)));
+        h->tapsCap = taps.size();
+    }
+    if (!taps.empty()) {
+        ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+        ORBX_HIP_CHECK(hipMemcpy(h->dTaps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    }
+    h->geomValid = true;
+    h->scratchSig = 0;  // force a scratch size check
+    return ORBX_OK;
+}
+
+int ensure_scratch(orbx_handle* h, int batch) {
+    const Geom& g = h->g;
+    const size_t sig = (size_t)g.w * 73856093u ^ (size_t)g.h * 19349663u;
+    if (h->scratchSig == sig && batch <= h->scratchBatch) return ORBX_OK;
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    free_dev(h->dPyr); free_dev(h->dBlur); free_dev(h->dCellCount); free_dev(h->dSlots);
+    free_dev(h->dKeyPacked); free_dev(h->dKeyNode); free_dev(h->dSel); free_dev(h->dSelCount);
+    h->dPyr = h->dBlur = nullptr;
+    h->dCellCount = h->dSlots = h->dKeyPacked = h->dSel = nullptr;
+    h->dKeyNode = nullptr;
+    h->dSelCount = nullptr;
+    h->scratchBatch = 0;
+    const size_t B = (size_t)batch;
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->dPyr, B * g.pyrFrameBytes + 256));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->dBlur, B * g.blurFrameBytes + 256));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->dCellCount, B * g.totalCells * sizeof(u32)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->dSlots, B * g.totalSlots * sizeof(u32)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->dKeyPacked, B * g.totalSlots * sizeof(u32)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->dKeyNode, B * g.totalSlots * sizeof(u16)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->dSel, B * g.totalSel * sizeof(u32)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->dSelCount, B * ORBX_MAX_LEVELS * sizeof(int)));
+    h->scratchBatch = batch;
+    h->scratchSig = sig;
+    return ORBX_OK;
+}
+
+struct StageTimer {
+    orbx_handle* h;
+    int stage;
+    hipEvent_t stop = nullptr;
+    StageTimer(orbx_handle* h_, int stage_) : h(h_), stage(stage_) {
+        if (!h->profiling) return;
+        StageProfile& p = h->prof;
+        if (p.used[stage] == p.ev[stage].size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            p.ev[stage].push_back(std::make_pair(a, b));
+        }
+        std::pair<hipEvent_t, hipEvent_t>& e = p.ev[stage][p.used[stage]++];
+        (void)hipEventRecord(e.first, h->stream);
+        stop = e.second;
+    }
+    ~StageTimer() {
+        if (stop) (void)hipEventRecord(stop, h->stream);
+    }
+};
+
+// Enqueue the whole pipeline for `n` frames starting at device image img0.
+int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc, int cap, int* dN) {
+    const Geom& g = h->g;
+    hipStream_t st = h->stream;
+    {
+        StageTimer t(h, ORBX_STAGE_PYRAMID);
+        for (int l = 1; l < g.nlevels; l++) {
+            ImgRef src = img0;
+            if (l > 1) {
+                src.base = h->dPyr + g.lv[l - 1].pyrOff;
+                src.frameStride = g.pyrFrameBytes;
+                src.pitch = g.lv[l - 1].pyrPitch;
+            }
+            const LevelGeom& L = g.lv[l];
+            dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, n), block(64, 4, 1);
+            hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, h->dPyr + L.pyrOff, L.pyrPitch,
+                               g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l], h->dTaps + h->tapYOff[l]);
+        }
+    }
+    {
+        StageTimer t(h, ORBX_STAGE_FAST);
+        dim3 grid(g.totalCells, n, 1), block(64, 1, 1);
+        hipLaunchKernelGGL(k_fast, grid, block, 0, st, g, img0, (const u8*)h->dPyr, h->dCellCount, h->dSlots,
+                           h->cfg.ini_th_fast, h->cfg.min_th_fast);
+    }
+    {
+        StageTimer t(h, ORBX_STAGE_QUADTREE);
+        dim3 grid(g.nlevels, n, 1), block(256, 1, 1);
+        hipLaunchKernelGGL(k_quadtree, grid, block, h->qtLds, st, g, (const u32*)h->dCellCount,
+                           (const u32*)h->dSlots, h->dKeyPacked, h->dKeyNode, h->dSel, h->dSelCount, h->dErr);
+    }
+    {
+        StageTimer t(h, ORBX_STAGE_BLUR);
+        dim3 grid(g.totalBlurTiles, n, 1), block(256, 1, 1);
+        hipLaunchKernelGGL(k_blur, grid, block, 0, st, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                           h->gaussK[1], h->gaussK[2], h->gaussK[3]);
+    }
+    {
+        StageTimer t(h, ORBX_STAGE_DESCRIBE);
+        dim3 grid((std::min(cap, g.totalSel) + 3) / 4, n, 1), block(256, 1, 1);
+        hipLaunchKernelGGL(k_describe, grid, block, 0, st, g, img0, (const u8*)h->dPyr, (const u8*)h->dBlur,
+                           (const u32*)h->dSel, (const int*)h->dSelCount, dKps, dDesc, cap, dN, h->dErr);
+    }
+    ORBX_HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int check_device_error(orbx_handle* h) {
+    int e = 0;
+    ORBX_HIP_CHECK(hipMemcpyAsync(&e, h->dErr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (e) {
+        ORBX_HIP_CHECK(hipMemsetAsync(h->dErr, 0, sizeof(int), h->stream));
+        orbx_set_error(e == 2 ? "keypoint capacity per frame too small" : "quadtree node capacity exceeded");
+        return ORBX_ERR_CAPACITY;
+    }
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* orbx_version(void) { return "orbx 0.1 (gfx950)"; }
+
+int orbx_create(const orbx_config* cfg, orbx_handle** out) {
+    if (!cfg || !out) {
+        orbx_set_error("null argument");
+        return ORBX_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (cfg->nlevels < 1 || cfg->nlevels > ORBX_MAX_LEVELS || cfg->nfeatures < 1 ||
+        !(cfg->scale_factor > 1.0f) || cfg->max_batch < 1 || cfg->max_width < 1 || cfg->max_height < 1) {
+        orbx_set_error("invalid configuration");
+        return ORBX_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+        orbx_set_error("no usable HIP device (count=%d, requested %d)", ndev, cfg->device);
+        return ORBX_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) {
+        orbx_set_error("hipSetDevice(%d) failed", cfg->device);
+        return ORBX_ERR_NO_DEVICE;
+    }
+    orbx_handle* h = new orbx_handle();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    make_tables(h);
+    int rc = upload_constants();
+    if (rc == ORBX_OK && hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking) != hipSuccess) {
+        orbx_set_error("hipStreamCreate failed");
+        rc = ORBX_ERR_HIP;
+    }
+    h->stream = h->ownStream;
+    if (rc == ORBX_OK && (hipMalloc((void**)&h->dErr, sizeof(int)) != hipSuccess ||
+                          hipMemset(h->dErr, 0, sizeof(int)) != hipSuccess)) {
+        orbx_set_error("hipMalloc failed");
+        rc = ORBX_ERR_HIP;
+    }
+    if (rc == ORBX_OK) rc = compute_geometry(h, cfg->max_width, cfg->max_height);
+    if (rc == ORBX_OK) rc = ensure_scratch(h, cfg->max_batch);
+    if (rc != ORBX_OK) {
+        orbx_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return ORBX_OK;
+}
+
+void orbx_destroy(orbx_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_dev(h->dPyr); free_dev(h->dBlur); free_dev(h->dCellCount); free_dev(h->dSlots);
+    free_dev(h->dKeyPacked); free_dev(h->dKeyNode); free_dev(h->dSel); free_dev(h->dSelCount);
+    free_dev(h->dErr); free_dev(h->dTaps); free_dev(h->dImgStage); free_dev(h->dKpStage);
+    free_dev(h->dDescStage); free_dev(h->dNStage);
+    for (int s = 0; s < ORBX_STAGE_COUNT; s++)
+        for (auto& e : h->prof.ev[s]) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
+    delete h;
+}
+
+int orbx_set_stream(orbx_handle* h, void* hip_stream) {
+    if (!h) return ORBX_ERR_INVALID;
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->ownStream;
+    return ORBX_OK;
+}
+
+int orbx_synchronize(orbx_handle* h) {
+    if (!h) return ORBX_ERR_INVALID;
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return ORBX_OK;
+}
+
+int orbx_max_keypoints(const orbx_handle* h) { return h ? h->g.totalSel : 0; }
+int orbx_levels(const orbx_handle* h) { return h->cfg.nlevels; }
+float orbx_scale_factor(const orbx_handle* h) { return (float)(double)h->cfg.scale_factor; }
+const float* orbx_scale_factors(const orbx_handle* h) { return h->scale; }
+const float* orbx_inv_scale_factors(const orbx_handle* h) { return h->invScale; }
+const float* orbx_level_sigma2(const orbx_handle* h) { return h->sigma2; }
+const float* orbx_inv_level_sigma2(const orbx_handle* h) { return h->invSigma2; }
+const int32_t* orbx_features_per_level(const orbx_handle* h) { return h->quota; }
+
+int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh, size_t row_stride,
+                       size_t img_stride, orbx_keypoint* kps, uint8_t* desc, int cap_per_frame,
+                       int* n_out, int mem_space) {
+    if (!h || B < 0 || !n_out) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (B == 0) return ORBX_OK;
+    if (w <= 0 || hh <= 0 || !imgs) {
+        // an empty image returns silently (reference src/ORBextractor.cc:1055-1056)
+        if (mem_space == ORBX_MEM_HOST)
+            for (int f = 0; f < B; f++) n_out[f] = 0;
+        else
+            ORBX_HIP_CHECK(hipMemsetAsync(n_out, 0, sizeof(int) * B, h->stream));
+        return ORBX_OK;
+    }
+    if (!kps || !desc || cap_per_frame < 1 || row_stride < (size_t)w) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (w > h->cfg.max_width || hh > h->cfg.max_height) {
+        orbx_set_error("image %dx%d exceeds configured maximum %dx%d", w, hh, h->cfg.max_width, h->cfg.max_height);
+        return ORBX_ERR_CAPACITY;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    int rc = compute_geometry(h, w, hh);
+    if (rc) return rc;
+    const int chunk = std::min(B, h->cfg.max_batch);
+    rc = ensure_scratch(h, chunk);
+    if (rc) return rc;
+    const int cap = cap_per_frame;
+    if (mem_space == ORBX_MEM_HOST) {
+        const size_t imgBytes = (size_t)chunk * w * hh;
+        if (imgBytes > h->imgStageCap) {
+            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+            free_dev(h->dImgStage);
+            h->dImgStage = nullptr;
+            h->imgStageCap = 0;
+            ORBX_HIP_CHECK(hipMalloc((void**)&h->dImgStage, imgBytes + 256));
+            h->imgStageCap = imgBytes;
+        }
+        const size_t outN = (size_t)chunk * cap;
+        if (outN > h->outStageCap) {
+            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+            free_dev(h->dKpStage); free_dev(h->dDescStage); free_dev(h->dNStage);
+            h->dKpStage = nullptr; h->dDescStage = nullptr; h->dNStage = nullptr;
+            h->outStageCap = 0;
+            ORBX_HIP_CHECK(hipMalloc((void**)&h->dKpStage, outN * sizeof(orbx_keypoint)));
+            ORBX_HIP_CHECK(hipMalloc((void**)&h->dDescStage, outN * 32));
+            ORBX_HIP_CHECK(hipMalloc((void**)&h->dNStage, (size_t)h->cfg.max_batch * sizeof(int)));
+            h->outStageCap = outN;
+        }
+    }
+    for (int f0 = 0; f0 < B; f0 += chunk) {
+        const int n = std::min(chunk, B - f0);
+        ImgRef img0;
+        if (mem_space == ORBX_MEM_HOST) {
+            if (img_stride == row_stride * (size_t)hh) {
+                ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage, (size_t)w, imgs + (size_t)f0 * img_stride, row_stride,
+                                                (size_t)w, (size_t)hh * n, hipMemcpyHostToDevice, h->stream));
+            } else {
+                // frames are not back to back in host memory: copy one by one
+                for (int f = 0; f < n; f++)
+                    ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage + (size_t)f * w * hh, (size_t)w,
+                                                    imgs + (size_t)(f0 + f) * img_stride, row_stride, (size_t)w,
+                                                    (size_t)hh, hipMemcpyHostToDevice, h->stream));
+            }
+            img0.base = h->dImgStage;
+            img0.pitch = w;
+            img0.frameStride = (i64)w * hh;
+            rc = run_pass(h, img0, n, h->dKpStage, h->dDescStage, cap, h->dNStage);
+            if (rc) return rc;
+            ORBX_HIP_CHECK(hipMemcpyAsync(kps + (size_t)f0 * cap, h->dKpStage, (size_t)n * cap * sizeof(orbx_keypoint),
+                                          hipMemcpyDeviceToHost, h->stream));
+            ORBX_HIP_CHECK(hipMemcpyAsync(desc + (size_t)f0 * cap * 32, h->dDescStage, (size_t)n * cap * 32,
+                                          hipMemcpyDeviceToHost, h->stream));
+            ORBX_HIP_CHECK(hipMemcpyAsync(n_out + f0, h->dNStage, (size_t)n * sizeof(int), hipMemcpyDeviceToHost,
+                                          h->stream));
+            rc = check_device_error(h);
+            if (rc) return rc;
+        } else {
+            img0.base = imgs + (size_t)f0 * img_stride;
+            img0.pitch = (int)row_stride;
+            img0.frameStride = (i64)img_stride;
+            rc = run_pass(h, img0, n, kps + (size_t)f0 * cap, desc + (size_t)f0 * cap * 32, cap, n_out + f0);
+            if (rc) return rc;
+        }
+        h->lastImg0 = img0;
+        h->lastBatch = n;
+        h->lastFirstFrame = f0;
+    }
+    return ORBX_OK;
+}
+
+int orbx_extract(orbx_handle* h, const uint8_t* img, int w, int hh, size_t stride, orbx_keypoint* kps,
+                 uint8_t* desc, int cap, int* n_out) {
+    return orbx_extract_batch(h, img, 1, w, hh, stride, stride * (size_t)(hh > 0 ? hh : 0), kps, desc, cap, n_out,
+                              ORBX_MEM_HOST);
+}
+
+int orbx_get_level(orbx_handle* h, int frame, int level, const uint8_t** ptr, int* w, int* hh, size_t* stride) {
+    if (!h || !ptr || !h->geomValid || level < 0 || level >= h->g.nlevels) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    const int fl = frame - h->lastFirstFrame;
+    if (fl < 0 || fl >= h->lastBatch) {
+        orbx_set_error("frame %d is not resident (last pass held frames %d..%d)", frame, h->lastFirstFrame,
+                       h->lastFirstFrame + h->lastBatch - 1);
+        return ORBX_ERR_INVALID;
+    }
+    const LevelGeom& L = h->g.lv[level];
+    if (level == 0) {
+        *ptr = h->lastImg0.base + (i64)fl * h->lastImg0.frameStride;
+        if (stride) *stride = (size_t)h->lastImg0.pitch;
+    } else {
+        *ptr = h->dPyr + (i64)fl * h->g.pyrFrameBytes + L.pyrOff;
+        if (stride) *stride = (size_t)L.pyrPitch;
+    }
+    if (w) *w = L.w;
+    if (hh) *hh = L.h;
+    return ORBX_OK;
+}
+
+int orbx_profile_enable(orbx_handle* h, int on) {
+    if (!h) return ORBX_ERR_INVALID;
+    h->profiling = on != 0;
+    return ORBX_OK;
+}
+
+static int profile_collect(orbx_handle* h) {
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    StageProfile& p = h->prof;
+    for (int s = 0; s < ORBX_STAGE_COUNT; s++) {
+        for (size_t i = 0; i < p.used[s]; i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.ev[s][i].first, p.ev[s][i].second) == hipSuccess) {
+                p.ms[s] += ms;
+                p.launches[s]++;
+            }
+        }
+        p.used[s] = 0;
+    }
+    return ORBX_OK;
+}
+
+int orbx_profile_read(orbx_handle* h, float* ms, int* launches, int n) {
+    if (!h || !ms) return ORBX_ERR_INVALID;
+    int rc = profile_collect(h);
+    if (rc) return rc;
+    for (int s = 0; s < n && s < ORBX_STAGE_COUNT; s++) {
+        ms[s] = (float)h->prof.ms[s];
+        if (launches) launches[s] = h->prof.launches[s];
+    }
+    return ORBX_OK;
+}
+
+int orbx_profile_reset(orbx_handle* h) {
+    if (!h) return ORBX_ERR_INVALID;
+    int rc = profile_collect(h);
+    if (rc) return rc;
+    for (int s = 0; s < ORBX_STAGE_COUNT; s++) {
+        h->prof.ms[s] = 0;
+        h->prof.launches[s] = 0;
+    }
+    return ORBX_OK;
+}
+
+int orbx_debug_level(orbx_handle* h, int frame, int level, uint8_t* dst) {
+    const uint8_t* ptr = nullptr;
+    int w = 0, hh = 0;
+    size_t stride = 0;
+    int rc = orbx_get_level(h, frame + (h ? h->lastFirstFrame : 0), level, &ptr, &w, &hh, &stride);
+    if (rc) return rc;
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    ORBX_HIP_CHECK(hipMemcpy2D(dst, w, ptr, stride, w, hh, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+int orbx_debug_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, int* w, int* hh) {
+    if (!h || !dst || !h->geomValid || level < 0 || level >= h->g.nlevels || frame < 0 || frame >= h->lastBatch)
+        return ORBX_ERR_INVALID;
+    const LevelGeom& L = h->g.lv[level];
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    ORBX_HIP_CHECK(hipMemcpy2D(dst, L.w, h->dBlur + (i64)frame * h->g.blurFrameBytes + L.blurOff, L.blurPitch, L.w,
+                               L.h, hipMemcpyDeviceToHost));
+    if (w) *w = L.w;
+    if (hh) *hh = L.h;
+    return ORBX_OK;
+}
+
+int orbx_debug_candidates(orbx_handle* h, int frame, int level, int* xs, int* ys, int* resp, int cap, int* n) {
+    if (!h || !n || !h->geomValid || level < 0 || level >= h->g.nlevels || frame < 0 || frame >= h->lastBatch)
+        return ORBX_ERR_INVALID;
+    const Geom& g = h->g;
+    const LevelGeom& L = g.lv[level];
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<u32> cc(std::max(L.nCells, 1)), sl((size_t)std::max(L.nCells, 1) * L.cellCap);
+    if (L.nCells > 0) {
+        ORBX_HIP_CHECK(hipMemcpy(cc.data(), h->dCellCount + (size_t)frame * g.totalCells + L.cellBase,
+                                 (size_t)L.nCells * sizeof(u32), hipMemcpyDeviceToHost));
+        ORBX_HIP_CHECK(hipMemcpy(sl.data(), h->dSlots + (size_t)frame * g.totalSlots + L.slotBase,
+                                 (size_t)L.nCells * L.cellCap * sizeof(u32), hipMemcpyDeviceToHost));
+    }
+    int k = 0;
+    for (int c = 0; c < L.nCells; c++)
+        for (u32 i = 0; i < cc[c]; i++, k++) {
+            const u32 p = sl[(size_t)c * L.cellCap + i];
+            if (k < cap) {
+                xs[k] = ORBX_PX(p);
+                ys[k] = ORBX_PY(p);
+                resp[k] = ORBX_PR(p);
+            }
+        }
+    *n = k;
+    return ORBX_OK;
+}
+
+int orbx_debug_selected(orbx_handle* h, int frame, int level, int* xs, int* ys, int* resp, int cap, int* n) {
+    if (!h || !n || !h->geomValid || level < 0 || level >= h->g.nlevels || frame < 0 || frame >= h->lastBatch)
+        return ORBX_ERR_INVALID;
+    const Geom& g = h->g;
+    const LevelGeom& L = g.lv[level];
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    int cnt = 0;
+    ORBX_HIP_CHECK(hipMemcpy(&cnt, h->dSelCount + (size_t)frame * ORBX_MAX_LEVELS + level, sizeof(int),
+                             hipMemcpyDeviceToHost));
+    std::vector<u32> s(std::max(cnt, 1));
+    if (cnt > 0)
+        ORBX_HIP_CHECK(hipMemcpy(s.data(), h->dSel + (size_t)frame * g.totalSel + L.selBase, (size_t)cnt * sizeof(u32),
+                                 hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt && i < cap; i++) {
+        xs[i] = ORBX_PX(s[i]);
+        ys[i] = ORBX_PY(s[i]);
+        resp[i] = ORBX_PR(s[i]);
+    }
+    *n = cnt;
+    return ORBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1067 @@
+// 256-bit binary descriptor matching on MI355X (gfx950): keypoint grid,
+// windowed candidate search, the sequential-state matchers of the reference
+// (SearchForInitialization, SearchByProjection frame-to-frame) and a
+// brute-force 2-nearest-neighbour search.
+//
+// Replaces the grid functions of ORB_SLAM2::Frame (reference src/Frame.cc:
+// 302-317, 437-502) and ORB_SLAM2::ORBmatcher (reference src/ORBmatcher.cc).
+// Distances are XOR + popcount on 32/64-bit words (v_bcnt); nothing here is a
+// dense contraction, so the matrix cores are not used.
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "orbx_internal.h"
+
+namespace {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef unsigned long long u64;
+typedef long long i64;
+
+const int GRID_COLS = ORBM_GRID_COLS, GRID_ROWS = ORBM_GRID_ROWS, GRID_CELLS = GRID_COLS * GRID_ROWS;
+const int TH_HIGH = 100;      // reference src/ORBmatcher.cc:38
+const int TH_LOW = 50;        // :39
+const int HISTO_LENGTH = 30;  // :40
+
+struct DevFrame {
+    const orbx_keypoint* kps;
+    const u8* desc;
+    int n;
+    float minX, minY, maxX, maxY;
+    float invW, invH;  // mfGridElementWidthInv / HeightInv (reference src/Frame.cc:211-212)
+};
+
+__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+    return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+           __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+__device__ __forceinline__ int wave_excl_count(bool flag, int* total) {
+    const u64 m = __ballot(flag);
+    *total = __popcll(m);
+    return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
+}
+
+// ------------------------------------------------------------------ grid
+// Frame::PosInGrid + AssignFeaturesToGrid: one workgroup per frame.  Cell id
+// = ix*48 + iy so that a window's cells of one column are contiguous in the
+// CSR; items inside a cell keep ascending keypoint order.
+__global__ __launch_bounds__(1024) void k_grid_build(DevFrame f, int* cellStart, int* cellItems, u16* cellOf) {
+    __shared__ int hist[GRID_CELLS + 1];
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= GRID_CELLS; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < f.n; i += 1024) {
+        const orbx_keypoint kp = f.kps[i];
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kp.x, f.minX), f.invW));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kp.y, f.minY), f.invH));
+        u16 c = 0xFFFF;
+        if (px >= 0 && px < GRID_COLS && py >= 0 && py < GRID_ROWS) {
+            c = (u16)(px * GRID_ROWS + py);
+            atomicAdd(&hist[c], 1);
+        }
+        cellOf[i] = c;
+    }
+    __syncthreads();
+    // exclusive scan of 3072 counts: 3 per thread
+    int v[3], s = 0;
+    for (int k = 0; k < 3; k++) {
+        v[k] = hist[tid * 3 + k];
+        s += v[k];
+    }
+    int inc = s;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; k++) base += wsum[k];
+    int run = base + inc - s;
+    __syncthreads();
+    for (int k = 0; k < 3; k++) {
+        hist[tid * 3 + k] = run;
+        cellStart[tid * 3 + k] = run;
+        run += v[k];
+    }
+    if (tid == 1023) {
+        hist[GRID_CELLS] = run;
+        cellStart[GRID_CELLS] = run;
+    }
+    __syncthreads();
+    // rank inside the cell = number of earlier keypoints in the same cell
+    for (int i = tid; i < f.n; i += 1024) {
+        const u16 c = cellOf[i];
+        if (c == 0xFFFF) continue;
+        int r = 0;
+        for (int j = 0; j < i; j++) r += (cellOf[j] == c);
+        cellItems[hist[c] + r] = i;
+    }
+}
+
+// ------------------------------------------------------------------ window walk
+struct Window {
+    int x0, x1, y0, y1;
+    bool empty;
+};
+
+// Cell range of Frame::GetFeaturesInArea (reference src/Frame.cc:442-456).
+__device__ __forceinline__ Window window_cells(const DevFrame& f, float x, float y, float r) {
+    Window w;
+    w.empty = true;
+    w.x0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, f.minX), r), f.invW)));
+    if (w.x0 >= GRID_COLS) return w;
+    w.x1 = min(GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, f.minX), r), f.invW)));
+    if (w.x1 < 0) return w;
+    w.y0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, f.minY), r), f.invH)));
+    if (w.y0 >= GRID_ROWS) return w;
+    w.y1 = min(GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, f.minY), r), f.invH)));
+    if (w.y1 < 0) return w;
+    w.empty = w.x1 < w.x0 || w.y1 < w.y0;
+    return w;
+}
+
+struct Query {
+    float x, y, r;
+    int minLevel, maxLevel;
+    bool useRight;     // apply the right-image gate (reference src/ORBmatcher.cc:1615-1621)
+    float ur, rGate;
+};
+
+// One wave walks a query's window in the reference's order (ix outer, iy
+// inner, bucket order) and calls emit(pos, idx) for each accepted candidate
+// with its ordinal `pos`; returns the number accepted.  For one ix the
+// cells iy0..iy1 are a contiguous CSR run.
+template <typename Emit>
+__device__ __forceinline__ int walk_window(const DevFrame& f, const int* __restrict__ cellStart,
+                                           const int* __restrict__ cellItems, const float* __restrict__ uRight,
+                                           const Query& q, Emit emit) {
+    const Window w = window_cells(f, q.x, q.y, q.r);
+    if (w.empty) return 0;
+    const int lane = threadIdx.x & 63;
+    const bool checkLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
+    int count = 0;
+    for (int ix = w.x0; ix <= w.x1; ix++) {
+        const int b = cellStart[ix * GRID_ROWS + w.y0], e = cellStart[ix * GRID_ROWS + w.y1 + 1];
+        for (int base = b; base < e; base += 64) {
+            const int k = base + lane;
+            bool ok = false;
+            int idx = -1;
+            if (k < e) {
+                idx = cellItems[k];
+                const orbx_keypoint kp = f.kps[idx];
+                ok = true;
+                if (checkLevels) {
+                    if (kp.octave < q.minLevel) ok = false;
+                    if (q.maxLevel >= 0 && kp.octave > q.maxLevel) ok = false;
+                }
+                const float dx = __fsub_rn(kp.x, q.x), dy = __fsub_rn(kp.y, q.y);
+                if (!(fabsf(dx) < q.r && fabsf(dy) < q.r)) ok = false;
+                if (ok && q.useRight) {
+                    const float urk = uRight[idx];
+                    if (urk > 0) {
+                        const float er = fabsf(__fsub_rn(q.ur, urk));
+                        if (er > q.rGate) ok = false;
+                    }
+                }
+            }
+            int tot;
+            const int off = wave_excl_count(ok, &tot);
+            if (ok) emit(count + off, idx);
+            count += tot;
+        }
+    }
+    return count;
+}
+
+__device__ __forceinline__ int desc_distance(const u8* a, const u8* b) {
+    const uint4* pa = (const uint4*)a;
+    const uint4* pb = (const uint4*)b;
+    return hamming256(pa[0], pa[1], pb[0], pb[1]);
+}
+
+struct QueryArrays {
+    const float *x, *y, *r;
+    const int *minLevel, *maxLevel;
+    const u8* desc;  // may be null
+};
+
+// mode 0: counts only.  mode 1: fill rows of fixed capacity maxCand.  mode 2: fill CSR rows at offs[q].
+__global__ __launch_bounds__(256) void k_window(DevFrame train, const int* __restrict__ cellStart,
+                                                 const int* __restrict__ cellItems, QueryArrays qa, int nq,
+                                                 int mode, int maxCand, const int* __restrict__ offs,
+                                                 int* candIdx, int* candDist, int* counts) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    Query qq;
+    qq.x = qa.x[q];
+    qq.y = qa.y[q];
+    qq.r = qa.r[q];
+    qq.minLevel = qa.minLevel ? qa.minLevel[q] : -1;
+    qq.maxLevel = qa.maxLevel ? qa.maxLevel[q] : -1;
+    qq.useRight = false;
+    qq.ur = qq.rGate = 0.f;
+    const u8* qd = qa.desc ? qa.desc + (i64)q * 32 : nullptr;
+    i64 rowBase = 0;
+    int cap = 0;
+    if (mode == 1) {
+        rowBase = (i64)q * maxCand;
+        cap = maxCand;
+    } else if (mode == 2) {
+        rowBase = offs[q];
+        cap = offs[q + 1] - offs[q];
+    }
+    const int n = walk_window(train, cellStart, cellItems, nullptr, qq, [&](int pos, int idx) {
+        if (mode != 0 && pos < cap) {
+            candIdx[rowBase + pos] = idx;
+            if (candDist) candDist[rowBase + pos] = qd ? desc_distance(qd, train.desc + (i64)idx * 32) : 0;
+        }
+    });
+    if ((threadIdx.x & 63) == 0 && counts) counts[q] = n;
+}
+
+// Exclusive scan of n ints by one workgroup (n is a few thousand).
+__global__ __launch_bounds__(1024) void k_scan(const int* in, int* out, int n) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? in[i] : 0;
+        int inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int b = carry;
+        for (int k = 0; k < wv; k++) b += wsum[k];
+        if (i < n) out[i] = b + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry = b + inc;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+// ------------------------------------------------------------------ SearchByProjection (frames)
+struct ProjArgs {
+    const u8* valid;
+    const float *u, *v, *invz;
+    const u8* hasObs;
+    const float* curURight;
+    const float* scaleFactors;
+    float bf, th;
+    int direction;
+};
+
+__device__ __forceinline__ bool proj_query(const DevFrame& cur, const DevFrame& last, const ProjArgs& a, int i,
+                                           Query* q) {
+    // reference src/ORBmatcher.cc:1564-1598
+    if (!a.valid[i]) return false;
+    const float invzc = a.invz[i];
+    if (invzc < 0) return false;
+    const float u = a.u[i], v = a.v[i];
+    if (u < cur.minX || u > cur.maxX) return false;
+    if (v < cur.minY || v > cur.maxY) return false;
+    const int oct = last.kps[i].octave;
+    const float radius = __fmul_rn(a.th, a.scaleFactors[oct]);
+    q->x = u;
+    q->y = v;
+    q->r = radius;
+    if (a.direction == 1) {
+        q->minLevel = oct;
+        q->maxLevel = -1;
+    } else if (a.direction == 2) {
+        q->minLevel = 0;
+        q->maxLevel = oct;
+    } else {
+        q->minLevel = oct - 1;
+        q->maxLevel = oct + 1;
+    }
+    q->useRight = true;
+    q->ur = __fsub_rn(u, __fmul_rn(a.bf, invzc));
+    q->rGate = radius;
+    return true;
+}
+
+// Candidate lists of every last-frame point (mode 0: counts; mode 2: CSR fill
+// with distances).  The right-image gate is state-free and applied here.
+__global__ __launch_bounds__(256) void k_proj_candidates(DevFrame cur, DevFrame last, const int* __restrict__ cellStart,
+                                                          const int* __restrict__ cellItems, ProjArgs a, int mode,
+                                                          const int* __restrict__ offs, int* candIdx, int* candDist,
+                                                          int* counts) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= last.n) return;
+    Query q;
+    int n = 0;
+    if (proj_query(cur, last, a, i, &q)) {
+        const u8* qd = last.desc + (i64)i * 32;
+        const i64 rowBase = mode == 2 ? offs[i] : 0;
+        n = walk_window(cur, cellStart, cellItems, a.curURight, q, [&](int pos, int idx) {
+            if (mode == 2) {
+                candIdx[rowBase + pos] = idx;
+                candDist[rowBase + pos] = desc_distance(qd, cur.desc + (i64)idx * 32);
+            }
+        });
+    }
+    if ((threadIdx.x & 63) == 0 && mode == 0) counts[i] = n;
+}
+
+// reference src/ORBmatcher.cc:1849-1894
+__device__ void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2;
+            max2 = max1;
+            max1 = s;
+            ind3 = ind2;
+            ind2 = ind1;
+            ind1 = i;
+        } else if (s > max2) {
+            max3 = max2;
+            max2 = s;
+            ind3 = ind2;
+            ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+        ind3 = -1;
+    }
+}
+
+__device__ __forceinline__ int rot_bin(float a1, float a2) {
+    // reference src/ORBmatcher.cc:1639-1644
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// Wave-wide minimum of a 64-bit key.
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+// Sequential part of SearchByProjection(cur, last): queries in index order,
+// candidates of one query spread over the 64 lanes.  One wave.
+__global__ __launch_bounds__(64) void k_proj_resolve(DevFrame cur, DevFrame last, ProjArgs a,
+                                                       const int* __restrict__ offs, const int* __restrict__ candIdx,
+                                                       const int* __restrict__ candDist, int checkOri, int* claimed,
+                                                       u8* claimedObs, int* qBest, int* qBin, int* nmatchesOut) {
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int keep[3];
+    const int lane = threadIdx.x;
+    if (lane < HISTO_LENGTH) hist[lane] = 0;
+    __syncthreads();
+    int nmatches = 0;
+    for (int i = 0; i < last.n; i++) {
+        const int b = offs[i], e = offs[i + 1];
+        int best = -1;
+        if (e > b) {
+            u64 key = ~0ull;
+            for (int k = b + lane; k < e; k += 64) {
+                const int i2 = candIdx[k];
+                if (claimed[i2] >= 0 && claimedObs[i2]) continue;
+                const u64 kk = ((u64)(u32)candDist[k] << 32) | (u32)(k - b);
+                key = kk < key ? kk : key;
+            }
+            key = wave_min_u64(key);
+            // bestDist starts at 256 and only strictly smaller distances replace it
+            if (key != ~0ull && (int)(key >> 32) < 256 && (int)(key >> 32) <= TH_HIGH)
+                best = candIdx[b + (int)(key & 0xFFFFFFFFu)];
+        }
+        int bin = -1;
+        if (best >= 0) {
+            nmatches++;
+            if (checkOri) bin = rot_bin(last.kps[i].angle, cur.kps[best].angle);
+            if (lane == 0) {
+                claimed[best] = i;
+                claimedObs[best] = a.hasObs[i];
+                if (bin >= 0) hist[bin]++;
+            }
+            __threadfence_block();
+        }
+        if (lane == 0) {
+            qBest[i] = best;
+            qBin[i] = bin;
+        }
+    }
+    __syncthreads();
+    if (checkOri) {
+        if (lane == 0) {
+            int i1 = -1, i2 = -1, i3 = -1;
+            three_maxima(hist, HISTO_LENGTH, i1, i2, i3);
+            keep[0] = i1;
+            keep[1] = i2;
+            keep[2] = i3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int i = lane; i < last.n; i += 64) {
+            const int bin = qBin[i];
+            if (bin >= 0 && bin != keep[0] && bin != keep[1] && bin != keep[2]) {
+                claimed[qBest[i]] = -1;
+                claimedObs[qBest[i]] = 0;
+                removed++;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+        nmatches -= removed;
+    }
+    if (lane == 0) *nmatchesOut = nmatches;
+}
+
+// ------------------------------------------------------------------ SearchForInitialization
+// Sequential part (reference src/ORBmatcher.cc:515-591): one wave, queries in
+// index order; vMatchedDistance / vnMatches21 / vnMatches12 live in global
+// scratch written and read by this wave only.
+__global__ __launch_bounds__(64) void k_init_resolve(DevFrame f1, DevFrame f2, const int* __restrict__ offs,
+                                                       const int* __restrict__ candIdx, const int* __restrict__ candDist,
+                                                       float nnRatio, int checkOri, int* matchedDist, int* matches21,
+                                                       int* matches12, int* qBin, float* prevMatched, int* nmatchesOut) {
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int keep[3];
+    const int lane = threadIdx.x;
+    if (lane < HISTO_LENGTH) hist[lane] = 0;
+    for (int i = lane; i < f1.n; i += 64) {
+        matches12[i] = -1;
+        qBin[i] = -1;
+    }
+    for (int i = lane; i < f2.n; i += 64) {
+        matchedDist[i] = 0x7FFFFFFF;
+        matches21[i] = -1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    int nmatches = 0;
+    for (int i1 = 0; i1 < f1.n; i1++) {
+        const int b = offs[i1], e = offs[i1 + 1];
+        if (e <= b) continue;
+        // best = first minimum among admissible candidates; second = minimum of the rest
+        u64 key = ~0ull;
+        for (int k = b + lane; k < e; k += 64) {
+            const int i2 = candIdx[k];
+            const int d = candDist[k];
+            if (matchedDist[i2] <= d) continue;
+            const u64 kk = ((u64)(u32)d << 32) | (u32)(k - b);
+            key = kk < key ? kk : key;
+        }
+        key = wave_min_u64(key);
+        if (key == ~0ull) continue;
+        const int bestDist = (int)(key >> 32), bestPos = (int)(key & 0xFFFFFFFFu);
+        u64 key2 = ~0ull;
+        for (int k = b + lane; k < e; k += 64) {
+            if (k - b == bestPos) continue;
+            const int i2 = candIdx[k];
+            const int d = candDist[k];
+            if (matchedDist[i2] <= d) continue;
+            const u64 kk = (u64)(u32)d;
+            key2 = kk < key2 ? kk : key2;
+        }
+        key2 = wave_min_u64(key2);
+        const float second = key2 == ~0ull ? (float)0x7FFFFFFF : (float)(int)key2;
+        if (bestDist <= TH_LOW && (float)bestDist < __fmul_rn(second, nnRatio)) {
+            const int bestIdx2 = candIdx[b + bestPos];
+            const int prev = matches21[bestIdx2];
+            if (prev >= 0) nmatches--;
+            nmatches++;
+            int bin = -1;
+            if (checkOri) bin = rot_bin(f1.kps[i1].angle, f2.kps[bestIdx2].angle);
+            if (lane == 0) {
+                if (prev >= 0) matches12[prev] = -1;
+                matches12[i1] = bestIdx2;
+                matches21[bestIdx2] = i1;
+                matchedDist[bestIdx2] = bestDist;
+                qBin[i1] = bin;
+                if (bin >= 0) hist[bin]++;
+            }
+            __threadfence_block();
+        }
+    }
+    __syncthreads();
+    if (checkOri) {
+        if (lane == 0) {
+            int a = -1, b2 = -1, c = -1;
+            three_maxima(hist, HISTO_LENGTH, a, b2, c);
+            keep[0] = a;
+            keep[1] = b2;
+            keep[2] = c;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int i = lane; i < f1.n; i += 64) {
+            const int bin = qBin[i];
+            if (bin >= 0 && bin != keep[0] && bin != keep[1] && bin != keep[2] && matches12[i] >= 0) {
+                matches12[i] = -1;
+                removed++;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+        nmatches -= removed;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = lane; i < f1.n; i += 64) {
+        const int m = matches12[i];
+        if (m >= 0) {
+            prevMatched[2 * i] = f2.kps[m].x;
+            prevMatched[2 * i + 1] = f2.kps[m].y;
+        }
+    }
+    if (lane == 0) *nmatchesOut = nmatches;
+}
+
+// Queries of SearchForInitialization: level-0 keypoints of F1 search a window
+// around their previous match in F2 at level 0 (reference :515-523).
+__global__ void k_init_queries(DevFrame f1, const float* prevMatched, float window, float* qx, float* qy, float* qr,
+                               int* qmin, int* qmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= f1.n) return;
+    const bool use = f1.kps[i].octave <= 0;
+    qx[i] = prevMatched[2 * i];
+    qy[i] = prevMatched[2 * i + 1];
+    // a non-positive radius accepts nothing (|d| < r fails), which skips the query
+    qr[i] = use ? window : -1.f;
+    qmin[i] = 0;
+    qmax[i] = 0;
+}
+
+// ------------------------------------------------------------------ brute-force kNN-2
+#define KNN_QPT 2      // queries per thread
+#define KNN_TILE 256   // train descriptors per LDS tile
+
+// Each thread keeps KNN_QPT query descriptors in registers; train descriptors
+// stream through LDS in tiles and are read as wave-wide broadcasts.
+__global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt,
+                                               int indexBase, int* bestIdx, int* bestD, int* secondD) {
+    __shared__ uint4 tile[KNN_TILE * 2];
+    const int tid = threadIdx.x;
+    const int q0 = (blockIdx.x * 256 + tid) * KNN_QPT;
+    uint4 qa[KNN_QPT][2];
+    int best[KNN_QPT], second[KNN_QPT], idx[KNN_QPT];
+#pragma unroll
+    for (int k = 0; k < KNN_QPT; k++) {
+        const int qi = min(q0 + k, nq - 1);
+        qa[k][0] = q[(i64)qi * 2];
+        qa[k][1] = q[(i64)qi * 2 + 1];
+        best[k] = 256;
+        second[k] = 256;
+        idx[k] = -1;
+    }
+    for (int base = 0; base < nt; base += KNN_TILE) {
+        const int cnt = min(KNN_TILE, nt - base);
+        __syncthreads();
+        for (int i = tid; i < cnt * 2; i += 256) tile[i] = t[(i64)base * 2 + i];
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < cnt; j++) {
+            const uint4 b0 = tile[2 * j], b1 = tile[2 * j + 1];
+#pragma unroll
+            for (int k = 0; k < KNN_QPT; k++) {
+                const int d = hamming256(qa[k][0], qa[k][1], b0, b1);
+                const bool lt = d < best[k];
+                second[k] = lt ? best[k] : min(second[k], d);
+                idx[k] = lt ? base + j : idx[k];
+                best[k] = min(best[k], d);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KNN_QPT; k++) {
+        if (q0 + k < nq) {
+            bestIdx[q0 + k] = idx[k] < 0 ? -1 : idx[k] + indexBase;
+            bestD[q0 + k] = best[k];
+            secondD[q0 + k] = second[k];
+        }
+    }
+}
+
+// Serial scan over shard A then shard B, reproduced from the two partials:
+// best = min (A wins ties: lower global index); second = second smallest of
+// the union multiset = min(max(bestA, bestB), secondA, secondB).
+__global__ void k_knn2_merge(int nq, int* ia, int* da, int* sa, const int* ib, const int* db, const int* sb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int bA = da[i], bB = db[i];
+    const int s = min(max(bA, bB), min(sa[i], sb[i]));
+    if (bB < bA) {
+        da[i] = bB;
+        ia[i] = ib[i];
+    }
+    sa[i] = s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host
+struct orbm_context {
+    int device = 0;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    // grow-only scratch, one block per purpose
+    std::vector<std::pair<void*, size_t>> pool;
+};
+
+namespace {
+
+int pool_get(orbm_context* m, int slot, size_t bytes, void** out) {
+    if ((int)m->pool.size() <= slot) m->pool.resize(slot + 1, std::make_pair((void*)nullptr, (size_t)0));
+    std::pair<void*, size_t>& e = m->pool[slot];
+    if (e.second < bytes) {
+        ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        if (e.first) (void)hipFree(e.first);
+        e.first = nullptr;
+        e.second = 0;
+        const size_t want = std::max(bytes, (size_t)256) * 3 / 2;
+        ORBX_HIP_CHECK(hipMalloc(&e.first, want));
+        e.second = want;
+    }
+    *out = e.first;
+    return ORBX_OK;
+}
+
+enum {
+    SL_F1_KPS = 0, SL_F1_DESC, SL_F2_KPS, SL_F2_DESC, SL_CELL_START, SL_CELL_ITEMS, SL_CELL_OF, SL_QX, SL_QY,
+    SL_QR, SL_QMIN, SL_QMAX, SL_QDESC, SL_COUNTS, SL_OFFS, SL_CAND_IDX, SL_CAND_DIST, SL_STATE_A, SL_STATE_B,
+    SL_STATE_C, SL_STATE_D, SL_PREV, SL_SCALAR, SL_VALID, SL_U, SL_V, SL_INVZ, SL_HASOBS, SL_URIGHT, SL_SF,
+    SL_KNN_Q, SL_KNN_T, SL_KNN_I, SL_KNN_D, SL_KNN_S, SL_KNN_I2, SL_KNN_D2, SL_KNN_S2
+};
+
+// Device view of a caller array: the pointer itself for device memory, else a staged copy.
+template <typename T>
+int stage_in(orbm_context* m, int slot, const T* src, size_t count, int memSpace, const T** out) {
+    if (memSpace == ORBX_MEM_DEVICE || src == nullptr) {
+        *out = src;
+        return ORBX_OK;
+    }
+    void* d = nullptr;
+    int rc = pool_get(m, slot, std::max(count, (size_t)1) * sizeof(T), &d);
+    if (rc) return rc;
+    if (count) ORBX_HIP_CHECK(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, m->stream));
+    *out = (const T*)d;
+    return ORBX_OK;
+}
+
+template <typename T>
+int stage_out(orbm_context* m, int slot, T* dst, size_t count, int memSpace, T** out) {
+    if (memSpace == ORBX_MEM_DEVICE) {
+        *out = dst;
+        return ORBX_OK;
+    }
+    void* d = nullptr;
+    int rc = pool_get(m, slot, std::max(count, (size_t)1) * sizeof(T), &d);
+    if (rc) return rc;
+    *out = (T*)d;
+    return ORBX_OK;
+}
+
+template <typename T>
+int copy_back(orbm_context* m, T* host, const T* dev, size_t count, int memSpace) {
+    if (memSpace == ORBX_MEM_DEVICE || count == 0) return ORBX_OK;
+    ORBX_HIP_CHECK(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, m->stream));
+    return ORBX_OK;
+}
+
+int make_frame(orbm_context* m, const orbm_frame* f, int slotKps, int slotDesc, int memSpace, DevFrame* out) {
+    if (!f || f->n < 0 || (f->n > 0 && (!f->kps || !f->desc))) {
+        orbx_set_error("invalid frame");
+        return ORBX_ERR_INVALID;
+    }
+    if (f->n > 65000) {
+        orbx_set_error("frame has %d keypoints; limit is 65000", f->n);
+        return ORBX_ERR_UNSUPPORTED;
+    }
+    int rc = stage_in(m, slotKps, f->kps, (size_t)f->n, memSpace, &out->kps);
+    if (rc) return rc;
+    rc = stage_in(m, slotDesc, f->desc, (size_t)f->n * 32, memSpace, &out->desc);
+    if (rc) return rc;
+    out->n = f->n;
+    out->minX = f->min_x;
+    out->minY = f->min_y;
+    out->maxX = f->max_x;
+    out->maxY = f->max_y;
+    // reference src/Frame.cc:211-212
+    out->invW = static_cast<float>(GRID_COLS) / static_cast<float>(f->max_x - f->min_x);
+    out->invH = static_cast<float>(GRID_ROWS) / static_cast<float>(f->max_y - f->min_y);
+    return ORBX_OK;
+}
+
+int build_grid(orbm_context* m, const DevFrame& f, int** cellStart, int** cellItems) {
+    void *cs, *ci, *co;
+    int rc = pool_get(m, SL_CELL_START, (GRID_CELLS + 1) * sizeof(int), &cs);
+    if (rc) return rc;
+    rc = pool_get(m, SL_CELL_ITEMS, (size_t)std::max(f.n, 1) * sizeof(int), &ci);
+    if (rc) return rc;
+    rc = pool_get(m, SL_CELL_OF, (size_t)std::max(f.n, 1) * sizeof(u16), &co);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(1024), 0, m->stream, f, (int*)cs, (int*)ci, (u16*)co);
+    ORBX_HIP_CHECK(hipGetLastError());
+    *cellStart = (int*)cs;
+    *cellItems = (int*)ci;
+    return ORBX_OK;
+}
+
+int use_device(orbm_context* m) {
+    if (!m) {
+        orbx_set_error("null context");
+        return ORBX_ERR_INVALID;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbm_hamming256(const uint8_t* a, const uint8_t* b) {
+    int d = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t x, y;
+        memcpy(&x, a + 8 * i, 8);
+        memcpy(&y, b + 8 * i, 8);
+        d += __builtin_popcountll(x ^ y);
+    }
+    return d;
+}
+
+int orbm_create(int device, orbm_context** out) {
+    if (!out) return ORBX_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        orbx_set_error("no usable HIP device (count=%d, requested %d)", ndev, device);
+        return ORBX_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        orbx_set_error("hipSetDevice(%d) failed", device);
+        return ORBX_ERR_NO_DEVICE;
+    }
+    orbm_context* m = new orbm_context();
+    m->device = device;
+    if (hipStreamCreateWithFlags(&m->ownStream, hipStreamNonBlocking) != hipSuccess) {
+        delete m;
+        orbx_set_error("hipStreamCreate failed");
+        return ORBX_ERR_HIP;
+    }
+    m->stream = m->ownStream;
+    *out = m;
+    return ORBX_OK;
+}
+
+void orbm_destroy(orbm_context* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    for (auto& e : m->pool)
+        if (e.first) (void)hipFree(e.first);
+    if (m->ownStream) (void)hipStreamDestroy(m->ownStream);
+    delete m;
+}
+
+int orbm_set_stream(orbm_context* m, void* hip_stream) {
+    if (!m) return ORBX_ERR_INVALID;
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->stream = hip_stream ? (hipStream_t)hip_stream : m->ownStream;
+    return ORBX_OK;
+}
+
+int orbm_synchronize(orbm_context* m) {
+    if (!m) return ORBX_ERR_INVALID;
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_grid_build(orbm_context* m, const orbm_frame* f, int32_t* cell_start, int32_t* cell_items, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (!cell_start || !cell_items) return ORBX_ERR_INVALID;
+    DevFrame df;
+    rc = make_frame(m, f, SL_F2_KPS, SL_F2_DESC, mem_space, &df);
+    if (rc) return rc;
+    int *cs, *ci;
+    rc = build_grid(m, df, &cs, &ci);
+    if (rc) return rc;
+    if (mem_space == ORBX_MEM_DEVICE) {
+        ORBX_HIP_CHECK(hipMemcpyAsync(cell_start, cs, (GRID_CELLS + 1) * sizeof(int), hipMemcpyDeviceToDevice, m->stream));
+        if (df.n) ORBX_HIP_CHECK(hipMemcpyAsync(cell_items, ci, (size_t)df.n * sizeof(int), hipMemcpyDeviceToDevice, m->stream));
+    } else {
+        ORBX_HIP_CHECK(hipMemcpyAsync(cell_start, cs, (GRID_CELLS + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+        ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        const int total = cell_start[GRID_CELLS];
+        if (total) ORBX_HIP_CHECK(hipMemcpy(cell_items, ci, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}
+
+int orbm_window_candidates(orbm_context* m, const orbm_frame* train, const float* qx, const float* qy, const float* qr,
+                           const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* qdesc, int nq,
+                           int max_cand, int32_t* cand_idx, int32_t* cand_dist, int32_t* counts, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (nq < 0 || max_cand < 1 || !qx || !qy || !qr || !cand_idx || !counts) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (nq == 0) return ORBX_OK;
+    DevFrame df;
+    rc = make_frame(m, train, SL_F2_KPS, SL_F2_DESC, mem_space, &df);
+    if (rc) return rc;
+    int *cs, *ci;
+    rc = build_grid(m, df, &cs, &ci);
+    if (rc) return rc;
+    QueryArrays qa;
+    if ((rc = stage_in(m, SL_QX, qx, (size_t)nq, mem_space, &qa.x))) return rc;
+    if ((rc = stage_in(m, SL_QY, qy, (size_t)nq, mem_space, &qa.y))) return rc;
+    if ((rc = stage_in(m, SL_QR, qr, (size_t)nq, mem_space, &qa.r))) return rc;
+    if ((rc = stage_in(m, SL_QMIN, (const int*)qmin_level, (size_t)nq, mem_space, &qa.minLevel))) return rc;
+    if ((rc = stage_in(m, SL_QMAX, (const int*)qmax_level, (size_t)nq, mem_space, &qa.maxLevel))) return rc;
+    if ((rc = stage_in(m, SL_QDESC, qdesc, (size_t)nq * 32, mem_space, &qa.desc))) return rc;
+    int *dIdx, *dDist = nullptr, *dCnt;
+    const size_t rows = (size_t)nq * max_cand;
+    if ((rc = stage_out(m, SL_CAND_IDX, (int*)cand_idx, rows, mem_space, &dIdx))) return rc;
+    if (cand_dist && (rc = stage_out(m, SL_CAND_DIST, (int*)cand_dist, rows, mem_space, &dDist))) return rc;
+    if ((rc = stage_out(m, SL_COUNTS, (int*)counts, (size_t)nq, mem_space, &dCnt))) return rc;
+    hipLaunchKernelGGL(k_window, dim3((nq + 3) / 4), dim3(256), 0, m->stream, df, (const int*)cs, (const int*)ci, qa,
+                       nq, 1, max_cand, (const int*)nullptr, dIdx, dDist, dCnt);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)cand_idx, dIdx, rows, mem_space))) return rc;
+    if (cand_dist && (rc = copy_back(m, (int*)cand_dist, dDist, rows, mem_space))) return rc;
+    if ((rc = copy_back(m, (int*)counts, dCnt, (size_t)nq, mem_space))) return rc;
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const orbm_frame* f2, float* prev_matched_xy,
+                                   int32_t* matches12, int window_size, float nn_ratio, int check_orientation,
+                                   int* nmatches, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (!prev_matched_xy || !matches12 || !nmatches) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    DevFrame d1, d2;
+    if ((rc = make_frame(m, f1, SL_F1_KPS, SL_F1_DESC, mem_space, &d1))) return rc;
+    if ((rc = make_frame(m, f2, SL_F2_KPS, SL_F2_DESC, mem_space, &d2))) return rc;
+    *nmatches = 0;
+    if (d1.n == 0) return ORBX_OK;
+    int *cs, *ci;
+    if ((rc = build_grid(m, d2, &cs, &ci))) return rc;
+    const int n1 = d1.n, n2 = std::max(d2.n, 1);
+    float* dPrev;
+    void *qx, *qy, *qr, *qmin, *qmax, *cnt, *offs, *sA, *sB, *sC, *sD, *scal;
+    if (mem_space == ORBX_MEM_DEVICE) {
+        dPrev = prev_matched_xy;
+    } else {
+        void* p;
+        if ((rc = pool_get(m, SL_PREV, (size_t)n1 * 2 * sizeof(float), &p))) return rc;
+        dPrev = (float*)p;
+        ORBX_HIP_CHECK(hipMemcpyAsync(dPrev, prev_matched_xy, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    }
+    if ((rc = pool_get(m, SL_QX, (size_t)n1 * 4, &qx)) || (rc = pool_get(m, SL_QY, (size_t)n1 * 4, &qy)) ||
+        (rc = pool_get(m, SL_QR, (size_t)n1 * 4, &qr)) || (rc = pool_get(m, SL_QMIN, (size_t)n1 * 4, &qmin)) ||
+        (rc = pool_get(m, SL_QMAX, (size_t)n1 * 4, &qmax)) || (rc = pool_get(m, SL_COUNTS, (size_t)n1 * 4, &cnt)) ||
+        (rc = pool_get(m, SL_OFFS, (size_t)(n1 + 1) * 4, &offs)) || (rc = pool_get(m, SL_STATE_A, (size_t)n2 * 4, &sA)) ||
+        (rc = pool_get(m, SL_STATE_B, (size_t)n2 * 4, &sB)) || (rc = pool_get(m, SL_STATE_C, (size_t)n1 * 4, &sC)) ||
+        (rc = pool_get(m, SL_STATE_D, (size_t)n1 * 4, &sD)) || (rc = pool_get(m, SL_SCALAR, 64, &scal)))
+        return rc;
+    hipLaunchKernelGGL(k_init_queries, dim3((n1 + 255) / 256), dim3(256), 0, m->stream, d1, (const float*)dPrev,
+                       (float)window_size, (float*)qx, (float*)qy, (float*)qr, (int*)qmin, (int*)qmax);
+    QueryArrays qa = {(const float*)qx, (const float*)qy, (const float*)qr, (const int*)qmin, (const int*)qmax, d1.desc};
+    hipLaunchKernelGGL(k_window, dim3((n1 + 3) / 4), dim3(256), 0, m->stream, d2, (const int*)cs, (const int*)ci, qa, n1,
+                       0, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, n1);
+    int total = 0;
+    ORBX_HIP_CHECK(hipMemcpyAsync(&total, (int*)offs + n1, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    void *cIdx, *cDist;
+    if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
+        (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
+        return rc;
+    hipLaunchKernelGGL(k_window, dim3((n1 + 3) / 4), dim3(256), 0, m->stream, d2, (const int*)cs, (const int*)ci, qa, n1,
+                       2, 0, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr);
+    int* dM12;
+    if ((rc = stage_out(m, SL_STATE_C, (int*)matches12, (size_t)n1, mem_space, &dM12))) return rc;
+    hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), 0, m->stream, d1, d2, (const int*)offs, (const int*)cIdx,
+                       (const int*)cDist, nn_ratio, check_orientation, (int*)sA, (int*)sB, dM12, (int*)sD, dPrev,
+                       (int*)scal);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)matches12, (const int*)dM12, (size_t)n1, mem_space))) return rc;
+    if ((rc = copy_back(m, prev_matched_xy, (const float*)dPrev, (size_t)n1 * 2, mem_space))) return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, scal, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm_frame* last, const uint8_t* valid,
+                              const float* u, const float* v, const float* invz, const uint8_t* has_obs,
+                              const float* cur_u_right, const float* scale_factors, int nlevels, float bf, float th,
+                              int direction, int check_orientation, int32_t* cur_claimed, uint8_t* cur_claimed_obs,
+                              int* nmatches, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (!valid || !u || !v || !invz || !has_obs || !cur_u_right || !scale_factors || nlevels < 1 || !cur_claimed ||
+        !cur_claimed_obs || !nmatches) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    DevFrame dc, dl;
+    if ((rc = make_frame(m, cur, SL_F2_KPS, SL_F2_DESC, mem_space, &dc))) return rc;
+    if ((rc = make_frame(m, last, SL_F1_KPS, SL_F1_DESC, mem_space, &dl))) return rc;
+    *nmatches = 0;
+    if (dl.n == 0 || dc.n == 0) return ORBX_OK;
+    int *cs, *ci;
+    if ((rc = build_grid(m, dc, &cs, &ci))) return rc;
+    const int nl = dl.n, nc = dc.n;
+    ProjArgs a;
+    if ((rc = stage_in(m, SL_VALID, valid, (size_t)nl, mem_space, &a.valid)) ||
+        (rc = stage_in(m, SL_U, u, (size_t)nl, mem_space, &a.u)) || (rc = stage_in(m, SL_V, v, (size_t)nl, mem_space, &a.v)) ||
+        (rc = stage_in(m, SL_INVZ, invz, (size_t)nl, mem_space, &a.invz)) ||
+        (rc = stage_in(m, SL_HASOBS, has_obs, (size_t)nl, mem_space, &a.hasObs)) ||
+        (rc = stage_in(m, SL_URIGHT, cur_u_right, (size_t)nc, mem_space, &a.curURight)))
+        return rc;
+    {
+        // scale factors are a small host table in both memory spaces' callers; accept either
+        void* p;
+        if ((rc = pool_get(m, SL_SF, (size_t)nlevels * sizeof(float), &p))) return rc;
+        ORBX_HIP_CHECK(hipMemcpyAsync(p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyDefault, m->stream));
+        a.scaleFactors = (const float*)p;
+    }
+    a.bf = bf;
+    a.th = th;
+    a.direction = direction;
+    void *cnt, *offs, *qb, *qn, *scal;
+    if ((rc = pool_get(m, SL_COUNTS, (size_t)nl * 4, &cnt)) || (rc = pool_get(m, SL_OFFS, (size_t)(nl + 1) * 4, &offs)) ||
+        (rc = pool_get(m, SL_STATE_C, (size_t)nl * 4, &qb)) || (rc = pool_get(m, SL_STATE_D, (size_t)nl * 4, &qn)) ||
+        (rc = pool_get(m, SL_SCALAR, 64, &scal)))
+        return rc;
+    hipLaunchKernelGGL(k_proj_candidates, dim3((nl + 3) / 4), dim3(256), 0, m->stream, dc, dl, (const int*)cs, (const int*)ci,
+                       a, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, nl);
+    int total = 0;
+    ORBX_HIP_CHECK(hipMemcpyAsync(&total, (int*)offs + nl, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    void *cIdx, *cDist;
+    if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
+        (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
+        return rc;
+    hipLaunchKernelGGL(k_proj_candidates, dim3((nl + 3) / 4), dim3(256), 0, m->stream, dc, dl, (const int*)cs, (const int*)ci,
+                       a, 2, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr);
+    int* dClaim;
+    u8* dClaimObs;
+    if (mem_space == ORBX_MEM_DEVICE) {
+        dClaim = (int*)cur_claimed;
+        dClaimObs = cur_claimed_obs;
+    } else {
+        void *p1, *p2;
+        if ((rc = pool_get(m, SL_STATE_A, (size_t)nc * 4, &p1)) || (rc = pool_get(m, SL_STATE_B, (size_t)nc, &p2))) return rc;
+        dClaim = (int*)p1;
+        dClaimObs = (u8*)p2;
+        ORBX_HIP_CHECK(hipMemcpyAsync(dClaim, cur_claimed, (size_t)nc * 4, hipMemcpyHostToDevice, m->stream));
+        ORBX_HIP_CHECK(hipMemcpyAsync(dClaimObs, cur_claimed_obs, (size_t)nc, hipMemcpyHostToDevice, m->stream));
+    }
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), 0, m->stream, dc, dl, a, (const int*)offs, (const int*)cIdx,
+                       (const int*)cDist, check_orientation, dClaim, dClaimObs, (int*)qb, (int*)qn, (int*)scal);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)cur_claimed, (const int*)dClaim, (size_t)nc, mem_space))) return rc;
+    if ((rc = copy_back(m, cur_claimed_obs, (const u8*)dClaimObs, (size_t)nc, mem_space))) return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, scal, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int train_index_base,
+              int32_t* best_idx, int32_t* best_d, int32_t* second_d, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (nq < 0 || nt < 0 || !best_idx || !best_d || !second_d || (nq > 0 && !q) || (nt > 0 && !t)) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (nq == 0) return ORBX_OK;
+    if (((uintptr_t)q | (uintptr_t)t) & 15u) {
+        if (mem_space == ORBX_MEM_DEVICE) {
+            orbx_set_error("device descriptor arrays must be 16-byte aligned");
+            return ORBX_ERR_INVALID;
+        }
+    }
+    const u8 *dq, *dt;
+    if ((rc = stage_in(m, SL_KNN_Q, q, (size_t)nq * 32, mem_space, &dq))) return rc;
+    if ((rc = stage_in(m, SL_KNN_T, t, (size_t)nt * 32, mem_space, &dt))) return rc;
+    int *di, *dd, *ds;
+    if ((rc = stage_out(m, SL_KNN_I, (int*)best_idx, (size_t)nq, mem_space, &di))) return rc;
+    if ((rc = stage_out(m, SL_KNN_D, (int*)best_d, (size_t)nq, mem_space, &dd))) return rc;
+    if ((rc = stage_out(m, SL_KNN_S, (int*)second_d, (size_t)nq, mem_space, &ds))) return rc;
+    const int blocks = (nq + 256 * KNN_QPT - 1) / (256 * KNN_QPT);
+    hipLaunchKernelGGL(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt, nt,
+                       train_index_base, di, dd, ds);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)best_idx, (const int*)di, (size_t)nq, mem_space))) return rc;
+    if ((rc = copy_back(m, (int*)best_d, (const int*)dd, (size_t)nq, mem_space))) return rc;
+    if ((rc = copy_back(m, (int*)second_d, (const int*)ds, (size_t)nq, mem_space))) return rc;
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_knn2_merge(orbm_context* m, int nq, int32_t* best_idx_a, int32_t* best_d_a, int32_t* second_d_a,
+                    const int32_t* best_idx_b, const int32_t* best_d_b, const int32_t* second_d_b, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (nq < 0 || !best_idx_a || !best_d_a || !second_d_a || !best_idx_b || !best_d_b || !second_d_b) return ORBX_ERR_INVALID;
+    if (nq == 0) return ORBX_OK;
+    const int *ib, *db, *sb;
+    int *ia, *da, *sa;
+    if (mem_space == ORBX_MEM_DEVICE) {
+        ia = (int*)best_idx_a; da = (int*)best_d_a; sa = (int*)second_d_a;
+        ib = (const int*)best_idx_b; db = (const int*)best_d_b; sb = (const int*)second_d_b;
+    } else {
+        const int *t0, *t1, *t2;
+        if ((rc = stage_in(m, SL_KNN_I, (const int*)best_idx_a, (size_t)nq, mem_space, &t0)) ||
+            (rc = stage_in(m, SL_KNN_D, (const int*)best_d_a, (size_t)nq, mem_space, &t1)) ||
+            (rc = stage_in(m, SL_KNN_S, (const int*)second_d_a, (size_t)nq, mem_space, &t2)) ||
+            (rc = stage_in(m, SL_KNN_I2, (const int*)best_idx_b, (size_t)nq, mem_space, &ib)) ||
+            (rc = stage_in(m, SL_KNN_D2, (const int*)best_d_b, (size_t)nq, mem_space, &db)) ||
+            (rc = stage_in(m, SL_KNN_S2, (const int*)second_d_b, (size_t)nq, mem_space, &sb)))
+            return rc;
+        ia = (int*)t0; da = (int*)t1; sa = (int*)t2;
+    }
+    hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, ia, da, sa, ib, db, sb);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)best_idx_a, (const int*)ia, (size_t)nq, mem_space))) return rc;
+    if ((rc = copy_back(m, (int*)best_d_a, (const int*)da, (size_t)nq, mem_space))) return rc;
+    if ((rc = copy_back(m, (int*)second_d_a, (const int*)sa, (size_t)nq, mem_space))) return rc;
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+}  // extern "C"

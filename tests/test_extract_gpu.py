@@ -1,0 +1,166 @@
+"""Parity of the HIP extractor against the CPU oracle, through the C ABI.
+
+Bar: bit-exact keypoints (all seven fields), descriptors and their order.
+"""
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
+
+
+def assert_same_features(kps, desc, rk, rd, what=""):
+    assert len(kps) == len(rk), "%s keypoint count %d vs oracle %d" % (what, len(kps), len(rk))
+    for name in FIELDS:
+        bad = np.nonzero(kps[name] != rk[name])[0]
+        assert len(bad) == 0, "%s field %s differs at %s: %s vs %s" % (
+            what, name, bad[:5], kps[name][bad[:5]], rk[name][bad[:5]])
+    bad = np.nonzero((desc != rd).any(axis=1))[0]
+    assert len(bad) == 0, "%s %d descriptors differ (first %s)" % (what, len(bad), bad[:5])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_stages_vga(oracle, extractor_vga, seed):
+    ex = extractor_vga
+    p = oracle.params()
+    img = synth.synth_image(640, 480, seed)
+    kps, desc = ex(img, None)
+    for lvl in range(8):
+        ref = oracle.pyramid_level(p, img, lvl)
+        got = ex.image_pyramid_level(0, lvl)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref), "pyramid level %d differs in %d px" % (lvl, (got != ref).sum())
+        assert np.array_equal(ex.debug_blurred(0, lvl), oracle.gaussian7(ref)), "blur level %d" % lvl
+        rx, ry, rr = oracle.detect_cells(ref)
+        gx, gy, gr = ex.debug_candidates(0, lvl)
+        assert len(gx) == len(rx), "level %d: %d candidates vs %d" % (lvl, len(gx), len(rx))
+        assert np.array_equal(gx, rx) and np.array_equal(gy, ry) and np.array_equal(gr, rr)
+        h, w = ref.shape
+        sel = oracle.distribute(rx, ry, rr, 16, w - 16, 16, h - 16, int(ex.features_per_level()[lvl]))
+        sx, sy, sr = ex.debug_selected(0, lvl)
+        assert len(sx) == len(sel), "level %d: %d selected vs %d" % (lvl, len(sx), len(sel))
+        assert np.array_equal(sx, rx[sel] + 16) and np.array_equal(sy, ry[sel] + 16)
+        assert np.array_equal(sr, rr[sel])
+    rk, rd = oracle.extract(p, img)
+    assert_same_features(kps, desc, rk, rd, "seed %d" % seed)
+
+
+def test_getters(oracle, extractor_vga):
+    ex = extractor_vga
+    t = oracle.tables(oracle.params())
+    assert ex.GetLevels() == 8
+    assert ex.GetScaleFactor() == np.float32(1.2)
+    assert np.array_equal(ex.GetScaleFactors(), t["scale"])
+    assert np.array_equal(ex.GetInverseScaleFactors(), t["inv_scale"])
+    assert np.array_equal(ex.GetScaleSigmaSquares(), t["sigma2"])
+    assert np.array_equal(ex.GetInverseScaleSigmaSquares(), t["inv_sigma2"])
+    assert np.array_equal(ex.features_per_level(), t["quotas"])
+
+
+def test_batch_host_matches_single(oracle, extractor_vga):
+    ex = extractor_vga
+    imgs = synth.synth_batch(11, 640, 480, 100)  # 11 > max_batch=8: two internal passes
+    kps, desc, n = ex.extract_batch(imgs)
+    p = oracle.params()
+    for f in range(len(imgs)):
+        rk, rd = oracle.extract(p, imgs[f])
+        assert_same_features(kps[f, :n[f]], desc[f, :n[f]], rk, rd, "frame %d" % f)
+
+
+def test_batch_device_resident(oracle, extractor_vga):
+    import torch
+    ex = extractor_vga
+    imgs = synth.synth_batch(5, 640, 480, 200)
+    cap = ex.max_keypoints()
+    d_img = torch.from_numpy(imgs).cuda()
+    d_kps = torch.zeros(5 * cap * 28, dtype=torch.uint8, device="cuda")
+    d_desc = torch.zeros(5 * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(5, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d_img, d_kps, d_desc, d_n, cap)
+    ex.synchronize()
+    from slam_amd._lib import KP_DTYPE
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(KP_DTYPE).reshape(5, cap)
+    desc = d_desc.cpu().numpy().reshape(5, cap, 32)
+    p = oracle.params()
+    for f in range(5):
+        rk, rd = oracle.extract(p, imgs[f])
+        assert_same_features(kps[f, :n[f]], desc[f, :n[f]], rk, rd, "frame %d" % f)
+
+
+def test_strided_input(oracle, extractor_vga):
+    big = np.zeros((480, 700), np.uint8)
+    img = synth.synth_image(640, 480, 9)
+    big[:, 30:670] = img
+    view = big[:, 30:670]
+    kps, desc = extractor_vga(view, None)
+    rk, rd = oracle.extract(oracle.params(), img)
+    assert_same_features(kps, desc, rk, rd, "strided")
+
+
+def test_flat_image_uses_fallback_and_finds_nothing(extractor_vga):
+    img = np.full((480, 640), 90, np.uint8)
+    kps, desc = extractor_vga(img, None)
+    assert len(kps) == 0 and desc.shape == (0, 32)
+
+
+def test_empty_image(extractor_vga):
+    kps, desc = extractor_vga(np.zeros((0, 0), np.uint8), None)
+    assert len(kps) == 0 and desc.shape == (0, 32)
+
+
+def test_low_contrast_image_takes_min_threshold(oracle, extractor_vga):
+    # contrast between the two FAST thresholds: only the fallback threshold fires
+    img = (synth.synth_image(640, 480, 21).astype(np.int32) // 12 + 100).astype(np.uint8)
+    kps, desc = extractor_vga(img, None)
+    rk, rd = oracle.extract(oracle.params(), img)
+    assert_same_features(kps, desc, rk, rd, "low contrast")
+    assert len(kps) > 0
+
+
+def test_sparse_corners_fewer_than_quota(oracle, extractor_vga):
+    img = np.full((480, 640), 40, np.uint8)
+    img[100:140, 100:180] = 200
+    img[300:380, 400:430] = 220
+    img[200:210, 50:600] = 10
+    kps, desc = extractor_vga(img, None)
+    rk, rd = oracle.extract(oracle.params(), img)
+    assert 0 < len(rk) < 1000
+    assert_same_features(kps, desc, rk, rd, "sparse")
+
+
+@pytest.mark.parametrize("w,h,nf", [(1241, 376, 2000), (320, 240, 500), (752, 480, 1200)])
+def test_other_shapes(oracle, w, h, nf):
+    from slam_amd.extractor import ORBextractor
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+    try:
+        imgs = synth.synth_batch(2, w, h, 300 + w)
+        kps, desc, n = ex.extract_batch(imgs)
+        p = oracle.params(nfeatures=nf)
+        for f in range(2):
+            rk, rd = oracle.extract(p, imgs[f], cap=nf + 128)
+            assert_same_features(kps[f, :n[f]], desc[f, :n[f]], rk, rd, "%dx%d frame %d" % (w, h, f))
+    finally:
+        ex.close()
+
+
+def test_smaller_image_than_configured(oracle, extractor_vga):
+    img = synth.synth_image(400, 300, 5)
+    kps, desc = extractor_vga(img, None)
+    rk, rd = oracle.extract(oracle.params(), img)
+    assert_same_features(kps, desc, rk, rd, "400x300")
+    # and back to the configured size
+    img = synth.synth_image(640, 480, 6)
+    kps, desc = extractor_vga(img, None)
+    rk, rd = oracle.extract(oracle.params(), img)
+    assert_same_features(kps, desc, rk, rd, "640x480 again")
+
+
+def test_too_large_image_is_rejected(extractor_vga):
+    from slam_amd._lib import OrbxError
+    with pytest.raises(OrbxError):
+        extractor_vga(np.zeros((481, 640), np.uint8), None)
