@@ -90,6 +90,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OrbxError("HIP library %s not built: run `python -c 'import __graft_entry__ as g; "
                         "g.build()'` (there is no CPU fallback)" % LIB_PATH)
+    # A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own copy of
+    # libamdhip64 (same soname as the system one); importing torch first makes the
+    # loader resolve this library's HIP dependency to that already-loaded copy, so
+    # torch tensors and these kernels share one runtime and one device context.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported: no partial library
