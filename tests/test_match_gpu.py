@@ -1,0 +1,239 @@
+"""Parity of the HIP grid / matchers against the CPU oracle, through the C ABI.
+
+Bar: bit-exact indices, distances, match arrays and match counts.
+"""
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BOUNDS = (0.0, 0.0, 640.0, 480.0)
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    from slam_amd.matcher import ORBmatcher
+    m = ORBmatcher(0.9, True)
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def frames(oracle):
+    """Two overlapping views of one synthetic scene, features from the oracle."""
+    p = oracle.params()
+    sf = oracle.tables(p)["scale"]
+    scene = synth.synth_image(700, 520, 77)
+    a = np.ascontiguousarray(scene[20:500, 30:670])
+    b = np.ascontiguousarray(scene[26:506, 21:661])  # shifted by (+9, -6) px
+    ka, da = oracle.extract(p, a)
+    kb, db = oracle.extract(p, b)
+    return dict(sf=sf, a=(ka, da), b=(kb, db), shift=(9.0, -6.0))
+
+
+def views(frames, oracle):
+    from slam_amd.matcher import FrameView
+    (ka, da), (kb, db) = frames["a"], frames["b"]
+    ga = FrameView(ka, da, BOUNDS, frames["sf"])
+    gb = FrameView(kb, db, BOUNDS, frames["sf"])
+    oa = oracle.FrameData(ka, da, BOUNDS, frames["sf"])
+    ob = oracle.FrameData(kb, db, BOUNDS, frames["sf"])
+    return ga, gb, oa, ob
+
+
+def test_grid_build(oracle, matcher, frames):
+    ga, gb, oa, ob = views(frames, oracle)
+    for g, o in ((ga, oa), (gb, ob)):
+        s, it = matcher.AssignFeaturesToGrid(g)
+        rs, rit = oracle.grid_build(o)
+        assert np.array_equal(s, rs) and np.array_equal(it, rit)
+
+
+def test_grid_drops_out_of_bounds_points(oracle, matcher, frames):
+    from slam_amd.matcher import FrameView
+    ka, da = frames["a"]
+    k = ka.copy()
+    k["x"][:10] = 640.0   # round() lands on column 64: dropped
+    k["y"][10:20] = -3.0
+    g = FrameView(k, da, BOUNDS, frames["sf"])
+    o = oracle.FrameData(k, da, BOUNDS, frames["sf"])
+    s, it = matcher.AssignFeaturesToGrid(g)
+    rs, rit = oracle.grid_build(o)
+    assert s[-1] == rs[-1] < len(k)
+    assert np.array_equal(s, rs) and np.array_equal(it, rit)
+
+
+def test_features_in_area(oracle, matcher, frames):
+    ga, gb, oa, ob = views(frames, oracle)
+    rs, rit = oracle.grid_build(ob)
+    rng = np.random.RandomState(3)
+    nq = 300
+    x = rng.uniform(-40, 700, nq).astype(np.float32)
+    y = rng.uniform(-40, 520, nq).astype(np.float32)
+    r = rng.choice([7.0, 15.0, 36.5, 100.0], nq).astype(np.float32)
+    mn = rng.choice([-1, 0, 1, 3], nq).astype(np.int32)
+    mx = rng.choice([-1, 0, 2, 7], nq).astype(np.int32)
+    qd = synth.synth_descriptors(nq, 5)
+    idx, dist = matcher.GetFeaturesInArea(gb, x, y, r, mn, mx, qdesc=qd)
+    total = 0
+    for q in range(nq):
+        ref = oracle.features_in_area(ob, rs, rit, x[q], y[q], r[q], int(mn[q]), int(mx[q]))
+        assert np.array_equal(idx[q], ref), "query %d" % q
+        for k, i2 in enumerate(ref):
+            assert dist[q][k] == oracle.hamming256(qd[q], ob.desc[i2])
+        total += len(ref)
+    assert total > 1000
+
+
+def test_hamming_host(oracle):
+    from slam_amd.matcher import ORBmatcher
+    d = synth.synth_descriptors(64, 11)
+    for i in range(0, 64, 2):
+        assert ORBmatcher.DescriptorDistance(d[i], d[i + 1]) == oracle.hamming256(d[i], d[i + 1])
+    assert ORBmatcher.DescriptorDistance(d[0], d[0]) == 0
+    assert ORBmatcher.DescriptorDistance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+
+
+@pytest.mark.parametrize("ratio,ori,window", [(0.9, True, 100), (0.9, False, 100), (0.7, True, 30)])
+def test_search_for_initialization(oracle, frames, ratio, ori, window):
+    from slam_amd.matcher import ORBmatcher
+    ga, gb, oa, ob = views(frames, oracle)
+    m = ORBmatcher(ratio, ori)
+    prev = np.stack([ga.kps["x"], ga.kps["y"]], axis=1)
+    n, m12, pm = m.SearchForInitialization(ga, gb, prev, window)
+    rn, rm12, rpm = oracle.search_for_initialization(oa, ob, prev, window, ratio, ori)
+    assert n == rn and n > 20
+    assert np.array_equal(m12, rm12)
+    assert np.array_equal(pm, rpm.reshape(-1, 2))
+    # second call, as Tracking does on the next frame, starts from the updated positions
+    n2, m12b, _ = m.SearchForInitialization(ga, gb, pm, window)
+    rn2, rm12b, _ = oracle.search_for_initialization(oa, ob, rpm, window, ratio, ori)
+    assert n2 == rn2 and np.array_equal(m12b, rm12b)
+    m.close()
+
+
+def projection_inputs(frames, seed, frac_no_obs=0.3, stereo=True):
+    (ka, da), (kb, db) = frames["a"], frames["b"]
+    rng = np.random.RandomState(seed)
+    nl = len(ka)
+    dx, dy = frames["shift"]
+    valid = (rng.uniform(size=nl) < 0.8).astype(np.uint8)
+    u = (ka["x"] + dx + rng.normal(0, 1.0, nl)).astype(np.float32)
+    v = (ka["y"] + dy + rng.normal(0, 1.0, nl)).astype(np.float32)
+    invz = rng.uniform(0.05, 1.0, nl).astype(np.float32)
+    invz[rng.uniform(size=nl) < 0.02] = -0.1  # behind the camera
+    has_obs = (rng.uniform(size=nl) > frac_no_obs).astype(np.uint8)
+    ur = np.full(len(kb), -1.0, np.float32)
+    if stereo:
+        pick = rng.uniform(size=len(kb)) < 0.5
+        ur[pick] = (kb["x"][pick] - rng.uniform(0, 40, pick.sum())).astype(np.float32)
+    return valid, u, v, invz, has_obs, ur
+
+
+@pytest.mark.parametrize("direction,th,ori", [(0, 15.0, True), (0, 7.0, True), (1, 15.0, True),
+                                             (2, 15.0, False)])
+def test_search_by_projection_frames(oracle, frames, direction, th, ori):
+    from slam_amd.matcher import FrameView, ORBmatcher
+    (ka, da), (kb, db) = frames["a"], frames["b"]
+    valid, u, v, invz, has_obs, ur = projection_inputs(frames, 5 + direction)
+    cur = FrameView(kb, db, BOUNDS, frames["sf"], u_right=ur)
+    last = FrameView(ka, da, BOUNDS, frames["sf"])
+    ocur = oracle.FrameData(kb, db, BOUNDS, frames["sf"])
+    olast = oracle.FrameData(ka, da, BOUNDS, frames["sf"])
+    bf = 40.0
+    m = ORBmatcher(0.9, ori)
+    n, cl, co = m.SearchByProjection(cur, last, th, valid, u, v, invz, has_obs, bf, direction)
+    rn, rcl, rco = oracle.search_by_projection_frames(ocur, olast, valid, u, v, invz, has_obs, ur,
+                                                      bf, th, direction, ori)
+    assert n == rn and n > 50
+    assert np.array_equal(cl, rcl)
+    assert np.array_equal(co, rco)
+    m.close()
+
+
+def test_search_by_projection_with_prior_claims(oracle, frames):
+    from slam_amd.matcher import FrameView, ORBmatcher
+    (ka, da), (kb, db) = frames["a"], frames["b"]
+    valid, u, v, invz, has_obs, ur = projection_inputs(frames, 42, stereo=False)
+    rng = np.random.RandomState(1)
+    claimed = np.full(len(kb), -1, np.int32)
+    cobs = np.zeros(len(kb), np.uint8)
+    pick = rng.uniform(size=len(kb)) < 0.3
+    claimed[pick] = 0
+    cobs[pick] = (rng.uniform(size=pick.sum()) < 0.5).astype(np.uint8)
+    cur = FrameView(kb, db, BOUNDS, frames["sf"], u_right=ur)
+    last = FrameView(ka, da, BOUNDS, frames["sf"])
+    ocur = oracle.FrameData(kb, db, BOUNDS, frames["sf"])
+    olast = oracle.FrameData(ka, da, BOUNDS, frames["sf"])
+    m = ORBmatcher(0.9, True)
+    n, cl, co = m.SearchByProjection(cur, last, 15.0, valid, u, v, invz, has_obs, 40.0, 0,
+                                     claimed=claimed, claimed_obs=cobs)
+    rn, rcl, rco = oracle.search_by_projection_frames(ocur, olast, valid, u, v, invz, has_obs, ur,
+                                                      40.0, 15.0, 0, True, claimed, cobs)
+    assert n == rn
+    assert np.array_equal(cl, rcl)
+    m.close()
+
+
+def test_empty_frames(matcher, frames):
+    from slam_amd.matcher import FrameView
+    from slam_amd._lib import KP_DTYPE
+    e = FrameView(np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8), BOUNDS, frames["sf"])
+    ka, da = frames["a"]
+    g = FrameView(ka, da, BOUNDS, frames["sf"])
+    n, m12, _ = matcher.SearchForInitialization(e, g, np.zeros((0, 2), np.float32), 100)
+    assert n == 0 and len(m12) == 0
+    prev = np.stack([ka["x"], ka["y"]], axis=1)
+    n, m12, _ = matcher.SearchForInitialization(g, e, prev, 100)
+    assert n == 0 and (m12 == -1).all()
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (513, 1000), (2048, 4099), (300, 70000)])
+def test_knn2_small(oracle, matcher, nq, nt):
+    q = synth.synth_descriptors(nq, 100 + nq)
+    t = synth.synth_descriptors(nt, 200 + nt)
+    k = min(nq, nt) // 2
+    if k:
+        t[:k] = synth.perturb_descriptors(q[:k], 9)  # planted near-duplicates
+        t[k:2 * k] = t[:k][: len(t[k:2 * k])]        # and exact ties at a higher index
+    bi, bd, sd = matcher.knn2(q, t)
+    ri, rd, rs = oracle.knn2(q, t)
+    assert np.array_equal(bi, ri) and np.array_equal(bd, rd) and np.array_equal(sd, rs)
+
+
+def test_knn2_empty_train(matcher):
+    q = synth.synth_descriptors(10, 1)
+    bi, bd, sd = matcher.knn2(q, np.zeros((0, 32), np.uint8))
+    assert (bi == -1).all() and (bd == 256).all() and (sd == 256).all()
+
+
+def test_knn2_sharded_merge_equals_single(oracle, matcher):
+    q = synth.synth_descriptors(700, 31)
+    t = synth.synth_descriptors(6000, 32)
+    t[100:400] = synth.perturb_descriptors(q[:300], 3)
+    t[3100:3400] = t[100:400]  # duplicates across shards: the lower index must win
+    ri, rd, rs = oracle.knn2(q, t)
+    parts = [matcher.knn2(q, t[a:b], index_base=a) for a, b in ((0, 1500), (1500, 3000), (3000, 6000))]
+    acc = parts[0]
+    for p in parts[1:]:
+        acc = matcher.knn2_merge(acc, p)
+    assert np.array_equal(acc[0], ri) and np.array_equal(acc[1], rd) and np.array_equal(acc[2], rs)
+    # a duplicated best match also shows up as second best, so the ratio test rejects it
+    assert np.array_equal(acc[1][:300], acc[2][:300])
+    assert not matcher.ratio_test(acc[1], acc[2], 50)[:300].any()
+
+
+def test_knn2_large_roundtrip_property(matcher):
+    """At a size the oracle cannot finish: every planted duplicate is found with distance 0
+    at its planted index; the ratio test accepts it."""
+    import torch
+    n = 1 << 17
+    t = synth.synth_descriptors(n, 77)
+    perm = np.random.RandomState(0).permutation(n)
+    q = t[perm]
+    bi, bd, sd = matcher.knn2(q, t)
+    assert np.array_equal(bi, perm.astype(np.int32))
+    assert (bd == 0).all() and (sd > 60).all()
+    assert matcher.ratio_test(bd, sd, 50).all()
