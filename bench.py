@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ORB frames/s (640x480, 1000 kp, 8 levels) on N MI355X.
+
+One step = one pass of the extractor over this rank's batch of synthetic frames
+(4096 per GPU, resident in HBM when the timed region starts, outputs left in
+HBM).  Frames shard across ranks with no collective (weak scaling).  The JSON
+line also carries: per-stage HIP-event timings and the roofline of the
+dominant kernel, a CPU baseline (the oracle, on a bounded sample), a parity
+check of that sample, and Hamming pairs/s of the brute-force 2-NN search.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+W, H, NFEAT, NLEVELS = 640, 480, 1000, 8
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+# Algorithmic bytes per 640x480 frame of each stage (level sizes 640x480 ... 179x134):
+LEVEL_PX = [640 * 480, 533 * 400, 444 * 333, 370 * 278, 309 * 231, 257 * 193, 214 * 161, 179 * 134]
+ALG_BYTES = {
+    "pyramid": sum(LEVEL_PX[:-1]) + sum(LEVEL_PX[1:]),  # read levels 0..6, write levels 1..7
+    "fast": sum(LEVEL_PX),                              # every level read once
+    "blur": 2 * sum(LEVEL_PX),                          # read + write every level
+    "describe": NFEAT * (749 + 512 + 60),               # patch + test gathers + outputs per keypoint
+    "quadtree": None,                                   # latency-bound list logic; bytes are negligible
+}
+KERNEL_OF = {"pyramid": "k_resize (7 launches)", "fast": "k_fast", "quadtree": "k_quadtree",
+             "blur": "k_blur", "describe": "k_describe"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--chunk", type=int, default=512, help="frames per internal pass")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="sample size of the CPU baseline")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-hamming", action="store_true")
+    ap.add_argument("--knn", type=int, default=1 << 20, help="descriptors per side of the 2-NN search")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    from slam_amd import dist as sdist
+    from slam_amd import synth
+    from slam_amd._lib import KP_DTYPE
+    from slam_amd.extractor import ORBextractor
+    from slam_amd.matcher import ORBmatcher
+
+    rank, local_rank, world = sdist.init_process_group()
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    B = args.frames
+    ex = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, max_width=W, max_height=H,
+                      max_batch=min(args.chunk, B), device=local_rank)
+    stream = torch.cuda.current_stream()
+    ex.set_stream(stream.cuda_stream)
+    cap = ex.max_keypoints()
+
+    # synthetic frames, generated on the device (bit-identical to the numpy generator)
+    seed0 = 0x5EED0001 + rank * B
+    frames = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    for f0 in range(0, B, 128):
+        n = min(128, B - f0)
+        frames[f0:f0 + n] = synth.synth_batch_torch(n, W, H, seed0 + f0, device=dev)
+    d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def step():
+        ex.extract_batch_device(frames, d_kps, d_desc, d_n, cap)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ex.profile_enable(True)
+    ex.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ex.profile_enable(False)
+    prof = ex.profile_read()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_frames = world * B * args.steps
+    value = total_frames / elapsed
+
+    # ---- per-stage numbers and the roofline of the dominant kernel
+    stages = {}
+    passes = args.steps * ((B + ex.max_batch - 1) // ex.max_batch)
+    frames_per_launch = B * args.steps / passes
+    for name, (ms, launches) in prof.items():
+        per_launch_ms = ms / max(launches, 1)
+        ent = {"ms_total": round(ms, 3), "launches": launches, "ms_per_launch": round(per_launch_ms, 4),
+               "us_per_frame": round(1000.0 * ms / (B * args.steps), 4)}
+        if ALG_BYTES[name]:
+            ent["achieved_GBs"] = round(ALG_BYTES[name] * frames_per_launch / (per_launch_ms * 1e-3) / 1e9, 1)
+        stages[name] = ent
+    dominant = max(stages, key=lambda k: stages[k]["ms_total"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if dominant in tj and tj[dominant].get("frames_per_launch") == frames_per_launch:
+                traffic = tj[dominant]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    alg = ALG_BYTES[dominant]
+    ach = stages[dominant].get("achieved_GBs", 0.0)
+    roofline = {"kernel": KERNEL_OF[dominant], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(alg * frames_per_launch) if alg else None,
+                "avg_launch_ms": stages[dominant]["ms_per_launch"],
+                "time_share": round(stages[dominant]["ms_total"] / sum(s["ms_total"] for s in stages.values()), 3)}
+
+    out = {
+        "metric": "ORB frames/s (640x480, 1000kp, 8 lvl)", "value": round(value, 1), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "synthetic 640x480 batch of %d frames per GPU, ORB extraction "
+                               "(1000 features, 8 levels, scale 1.2, FAST 20/7), frames and outputs "
+                               "resident in HBM" % B,
+                   "frames_per_gpu": B, "frames_per_pass": ex.max_batch, "parallelism": "frames sharded, no collective"},
+        "roofline": roofline, "stages": stages,
+    }
+
+    # ---- CPU baseline + parity of the sample (rank 0, single-GPU run only)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from oracle import pyoracle as O
+        S = min(args.cpu_frames, B)
+        host = frames[:S].cpu().numpy()
+        threads = max(1, min(16, os.cpu_count() or 1))
+        p = O.params(NFEAT, 1.2, NLEVELS, 20, 7)
+        t1 = time.perf_counter()
+        rk, rd, rn = O.extract_batch(p, host, cap=cap, threads=threads)
+        cpu_mt = time.perf_counter() - t1
+        s1 = min(32, S)
+        t1 = time.perf_counter()
+        O.extract_batch(p, host[:s1], cap=cap, threads=1)
+        cpu_1t = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(S / cpu_mt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+                               "sample": "first %d of the benchmark's frames, oracle (C++ restatement of the "
+                                         "reference path, not OpenCV), frame-parallel std::thread" % S,
+                               "single_thread_frames_per_s": round(s1 / cpu_1t, 2)}
+        n = d_n[:S].cpu().numpy()
+        kps = d_kps[:S * cap * 28].cpu().numpy().view(KP_DTYPE).reshape(S, cap)
+        desc = d_desc[:S * cap * 32].cpu().numpy().reshape(S, cap, 32)
+        bad_kp = bad_desc = tot = 0
+        for f in range(S):
+            if n[f] != rn[f]:
+                bad_kp += max(n[f], rn[f])
+                tot += max(n[f], rn[f])
+                continue
+            tot += int(n[f])
+            same = np.ones(n[f], bool)
+            for fld in KP_DTYPE.names:
+                same &= kps[f, :n[f]][fld] == rk[f, :n[f]][fld]
+            bad_kp += int((~same).sum())
+            bad_desc += int((desc[f, :n[f]] != rd[f, :n[f]]).any(axis=1).sum())
+        out["parity"] = {"frames": S, "keypoints": tot, "mismatched_keypoints": bad_kp,
+                         "mismatched_descriptors": bad_desc}
+
+    # ---- Hamming pairs/s: brute-force 2-NN, train rows sharded over ranks
+    if not args.no_hamming:
+        m = ORBmatcher(0.6, True, device=local_rank)
+        m.set_stream(stream.cuda_stream)
+        NQ = NT = args.knn
+        nq_l = NQ // world
+        nt0, nt1 = sdist.shard_range(NT, rank, world)
+        g = torch.Generator(device=dev)
+        g.manual_seed(0xD35C + rank)
+        q_l = torch.randint(0, 256, (nq_l, 32), dtype=torch.uint8, device=dev, generator=g)
+        t_l = torch.randint(0, 256, (nt1 - nt0, 32), dtype=torch.uint8, device=dev, generator=g)
+
+        def local_knn2(q_all, t_loc, off):
+            bi = torch.empty(q_all.shape[0], dtype=torch.int32, device=dev)
+            bd = torch.empty_like(bi)
+            sd = torch.empty_like(bi)
+            m.knn2_device(q_all, t_loc, bi, bd, sd, off)
+            return bi, bd, sd
+
+        def merge(a, b):
+            m.knn2_merge_device(a[0], a[1], a[2], b[0], b[1], b[2])
+            return a
+
+        sdist.knn2_sharded(q_l, t_l, nt0, local_knn2, merge)  # warm-up
+        barrier()
+        t1 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            sdist.knn2_sharded(q_l, t_l, nt0, local_knn2, merge)
+        barrier()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        pairs = float(nq_l * world) * float(NT) * reps
+        int_peak = 256 * 4 * 32 * 2.4e9  # lanes x clock: 32-bit integer ops/s
+        out["hamming"] = {"pairs_per_s": round(pairs / dt, 1), "nq": nq_l * world, "nt": NT,
+                          "int_ops_per_pair": 16, "frac_of_int_valu_peak": round(pairs / dt * 16 / (int_peak * world), 4),
+                          "exchange": "all-gather queries + all-to-all partials (RCCL)" if world > 1 else "none"}
+        m.close()
+
+    if rank == 0:
+        print(json.dumps(out))
+    ex.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

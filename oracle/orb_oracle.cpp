@@ -272,25 +272,41 @@ void fast9_nms(const uint8_t* img, int w, int h, size_t stride, int threshold,
     for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
     const int K = 8, N = 25;
     std::vector<uint8_t> score((size_t)w * h, 0);
+    threshold = std::min(std::max(threshold, 0), 255);
+    uint8_t threshold_tab[512];
+    for (int i = -255; i <= 255; i++)
+        threshold_tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
     for (int i = 3; i < h - 3; i++) {
         const uint8_t* ptr = img + (size_t)i * stride + 3;
         for (int j = 3; j < w - 3; j++, ptr++) {
             int v = ptr[0];
+            const uint8_t* tab = &threshold_tab[0] - v + 255;
+            int d = tab[ptr[pixel[0]]] | tab[ptr[pixel[8]]];
+            if (d == 0) continue;
+            d &= tab[ptr[pixel[2]]] | tab[ptr[pixel[10]]];
+            d &= tab[ptr[pixel[4]]] | tab[ptr[pixel[12]]];
+            d &= tab[ptr[pixel[6]]] | tab[ptr[pixel[14]]];
+            if (d == 0) continue;
+            d &= tab[ptr[pixel[1]]] | tab[ptr[pixel[9]]];
+            d &= tab[ptr[pixel[3]]] | tab[ptr[pixel[11]]];
+            d &= tab[ptr[pixel[5]]] | tab[ptr[pixel[13]]];
+            d &= tab[ptr[pixel[7]]] | tab[ptr[pixel[15]]];
             bool corner = false;
-            int vt = v - threshold, count = 0;
-            for (int k = 0; k < N; k++) {
-                int x = ptr[pixel[k]];
-                if (x < vt) {
-                    if (++count > K) {
-                        corner = true;
-                        break;
-                    }
-                } else
-                    count = 0;
+            if (d & 1) {
+                int vt = v - threshold, count = 0;
+                for (int k = 0; k < N; k++) {
+                    int x = ptr[pixel[k]];
+                    if (x < vt) {
+                        if (++count > K) {
+                            corner = true;
+                            break;
+                        }
+                    } else
+                        count = 0;
+                }
             }
-            if (!corner) {
-                vt = v + threshold;
-                count = 0;
+            if (!corner && (d & 2)) {
+                int vt = v + threshold, count = 0;
                 for (int k = 0; k < N; k++) {
                     int x = ptr[pixel[k]];
                     if (x > vt) {

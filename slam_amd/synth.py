@@ -84,3 +84,85 @@ def perturb_descriptors(desc, seed, max_flips=30):
         rows = np.nonzero(nflip > j)[0]
         out[rows, bit[rows] >> 3] ^= (1 << (bit[rows] & 7)).astype(np.uint8)
     return out
+
+
+# ---------------------------------------------------------------- torch twin
+def _t_splitmix64(x):
+    """splitmix64 on torch int64 (two's-complement wrap == uint64 arithmetic)."""
+    import torch
+
+    def lsr(v, s):  # logical shift right
+        return (v >> s) & ((1 << (64 - s)) - 1)
+
+    c1 = torch.tensor(0x9E3779B97F4A7C15 - (1 << 64), dtype=torch.int64, device=x.device)
+    c2 = torch.tensor(0xBF58476D1CE4E5B9 - (1 << 64), dtype=torch.int64, device=x.device)
+    c3 = torch.tensor(0x94D049BB133111EB - (1 << 64), dtype=torch.int64, device=x.device)
+    x = x + c1
+    x = (x ^ lsr(x, 30)) * c2
+    x = (x ^ lsr(x, 27)) * c3
+    return x ^ lsr(x, 31)
+
+
+def _t_hash(seeds, n, stream):
+    """(B, n) int64 holding the same bits as hash_u64(seed, n, stream) per row."""
+    import torch
+    base = _t_splitmix64(seeds ^ (stream << 32))
+    c = torch.tensor(0xD1342543DE82EF95 - (1 << 64), dtype=torch.int64, device=seeds.device)
+    idx = torch.arange(n, dtype=torch.int64, device=seeds.device) * c
+    return _t_splitmix64(idx[None, :] + base[:, None])
+
+
+def _t_top_bits(v, bits):
+    return (v >> (64 - bits)) & ((1 << bits) - 1)
+
+
+def _t_umod(v, m):
+    """(uint64 view of v) % m for small positive m."""
+    hi = ((v >> 1) & 0x7FFFFFFFFFFFFFFF)  # floor(u / 2)
+    return ((hi % m) * 2 + (v & 1)) % m
+
+
+def synth_batch_torch(n, w, h, seed0, device="cpu", rects=64):
+    """Same bytes as synth_batch(n, w, h, seed0), computed with torch ops on `device`."""
+    import torch
+    import torch.nn.functional as F
+    seeds = torch.arange(seed0, seed0 + n, dtype=torch.int64, device=device)
+    ys = torch.arange(h, dtype=torch.int64, device=device)
+    xs = torch.arange(w, dtype=torch.int64, device=device)
+    bidx = torch.arange(n, device=device)[:, None, None]
+    acc = torch.zeros((n, h, w), dtype=torch.int64, device=device)
+    stream = 1
+    for block, weight in ((32, 96), (16, 64), (8, 56)):
+        gh, gw = (h + block - 1) // block + 1, (w + block - 1) // block + 1
+        g = _t_top_bits(_t_hash(seeds, gh * gw, stream), 8).reshape(n, gh, gw)
+        stream += 1
+        oy = _t_umod(_t_hash(seeds, 1, 100 + stream)[:, 0], block)
+        ox = _t_umod(_t_hash(seeds, 1, 200 + stream)[:, 0], block)
+        yi = (ys[None, :] + oy[:, None]) // block
+        xi = (xs[None, :] + ox[:, None]) // block
+        acc += weight * g[bidx, yi[:, :, None], xi[:, None, :]]
+    img = acc // 256
+    r = _t_hash(seeds, rects * 5, 50)
+    Y = ys[None, :, None]
+    X = xs[None, None, :]
+    for i in range(rects):
+        rw = 8 + _t_umod(r[:, 5 * i], max(8, w // 6))
+        rh = 8 + _t_umod(r[:, 5 * i + 1], max(8, h // 6))
+        x0 = _t_umod_vec(r[:, 5 * i + 2], torch.clamp(w - rw, min=1))
+        y0 = _t_umod_vec(r[:, 5 * i + 3], torch.clamp(h - rh, min=1))
+        val = _t_top_bits(r[:, 5 * i + 4], 8)
+        m = ((X >= x0[:, None, None]) & (X < (x0 + rw)[:, None, None]) &
+             (Y >= y0[:, None, None]) & (Y < (y0 + rh)[:, None, None]))
+        img = torch.where(m, val[:, None, None], img)
+    p = F.pad(img.to(torch.float32)[:, None], (1, 1, 1, 1), mode="replicate")[:, 0]
+    s = sum(p[:, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3))
+    img = (s.to(torch.int64) + 4) // 9
+    fine = _t_top_bits(_t_hash(seeds, w * h, 60), 3).reshape(n, h, w)
+    img = torch.clamp(img + fine - 3, 0, 255)
+    return img.to(torch.uint8)
+
+
+def _t_umod_vec(v, m):
+    """(uint64 view of v) % m with a per-row positive modulus tensor m."""
+    hi = ((v >> 1) & 0x7FFFFFFFFFFFFFFF)
+    return ((hi % m) * 2 + (v & 1)) % m
