@@ -42,6 +42,7 @@ struct LevelGeom {
     i64 blurOff;  // bytes into the per-frame blurred block
     int blurPitch;
     int blurTileBase, blurTilesX, blurTiles;
+    int blurGroups, blurBands, blurItemBase;  // streaming blur: 4-px column groups x row bands
     // FAST cells
     int nCols, nRows, wCell, hCell;
     int cellBase, nCells, cellCap, slotBase;
@@ -54,7 +55,7 @@ struct LevelGeom {
 
 struct Geom {
     int nlevels, w, h;
-    int totalCells, totalSlots, totalSel, totalBlurTiles;
+    int totalCells, totalSlots, totalSel, totalBlurTiles, totalBlurItems;
     i64 pyrFrameBytes, blurFrameBytes;
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
@@ -121,14 +122,16 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // Separable 7-tap integer Gaussian with reflect-101 borders.  Row sums fit 16
 // bits (257*255 = 65535); output = sat_u8((sum + 32768) >> 16).
 __global__ __launch_bounds__(256) void k_blur(Geom g, ImgRef img0, const u8* __restrict__ pyr,
-                                               u8* __restrict__ blur, int k0, int k1, int k2, int k3) {
+                                               u8* __restrict__ blur, int k0, int k1, int k2, int k3,
+                                               int tileOffset) {
     __shared__ u8 tin[BLUR_TH + 6][BLUR_TW + 8];
     __shared__ u16 hs[BLUR_TH + 6][BLUR_TW];
     const int f = blockIdx.y;
+    const int tileId = blockIdx.x + tileOffset;
     int l = 0;
-    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.lv[l + 1].blurTileBase) l++;
+    while (l + 1 < g.nlevels && tileId >= g.lv[l + 1].blurTileBase) l++;
     const LevelGeom& L = g.lv[l];
-    const int t = blockIdx.x - L.blurTileBase;
+    const int t = tileId - L.blurTileBase;
     const int tx0 = (t % L.blurTilesX) * BLUR_TW, ty0 = (t / L.blurTilesX) * BLUR_TH;
     const ImgRef im = level_image(g, l, img0, pyr);
     const u8* src = im.base + (i64)f * im.frameStride;
@@ -163,6 +166,98 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, ImgRef img0, const u8* __r
             out |= (u32)v << (8 * k);
         }
         *(u32*)(dst + (i64)oy * L.blurPitch + ox) = out;
+    }
+}
+
+#define BLUR_BH 28  // output rows per band (a multiple of the 7-row window)
+
+// Streaming form of the same filter: no LDS, no barriers.  A lane owns a column
+// of 4 pixels and walks down a band of rows keeping the last 7 horizontal sums
+// in registers.  Per row it loads three aligned 32-bit words (left, own, right
+// group); reflect-101 at the image's left/right edges is a per-lane byte
+// permutation fixed at start-up, at the top/bottom a reflected row index.
+// The 7 taps of a row are two 4-byte dot products (v_dot4_u32_u8).
+__global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const u8* __restrict__ pyr,
+                                                      u8* __restrict__ blur, int k0, int k1, int k2, int k3,
+                                                      int firstLevel) {
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    int l = firstLevel;
+    while (l + 1 < g.nlevels && item >= g.lv[l + 1].blurItemBase) l++;
+    const LevelGeom& L = g.lv[l];
+    const int it = item - L.blurItemBase;
+    const int G = L.blurGroups;
+    if (it < 0 || it >= G * L.blurBands) return;
+    const int band = it / G, gx = it - band * G;
+    const int w = L.w, h = L.h;
+    const ImgRef im = level_image(g, l, img0, pyr);
+    const u8* src = im.base + (i64)f * im.frameStride;
+    u8* dst = blur + (i64)f * g.blurFrameBytes + L.blurOff;
+    const int gl = max(gx - 1, 0), gr = min(gx + 1, G - 1);
+    const bool lastGroup = gx == G - 1;
+
+    // byte selectors for the 12 positions x = 4*gx-4 .. 4*gx+7
+    u32 selL = 0, selC = 0, selR = 0;
+#pragma unroll
+    for (int p = 0; p < 12; p++) {
+        const int x = 4 * gx - 4 + p;
+        const int xr = reflect101(min(max(x, -3), w + 2), w);
+        const int gs = xr >> 2, bs = xr & 3;
+        u32 code;
+        if (p < 8) {
+            // sources: S1 = left word (0..3), S0 = own word (4..7)
+            code = gs == gx ? 4 + bs : gs == gl ? bs : 4;
+        } else {
+            // sources: S1 = right word (left word for the last group), S0 = own word
+            const int ga = lastGroup ? gl : gr;
+            code = gs == gx ? 4 + bs : gs == ga ? bs : 4;
+        }
+        if (p < 4) selL |= code << (8 * p);
+        else if (p < 8) selC |= code << (8 * (p - 4));
+        else selR |= code << (8 * (p - 8));
+    }
+    const u32 W1 = (u32)k0 | ((u32)k1 << 8) | ((u32)k2 << 16) | ((u32)k3 << 24);
+    const u32 W2 = (u32)k2 | ((u32)k1 << 8) | ((u32)k0 << 16);
+    const int y0 = band * BLUR_BH;
+    const int yEnd = min(y0 + BLUR_BH, h);
+
+    u32 win[7][4];
+    auto load_row = [&](int y, u32* hs) {
+        const int r = reflect101(min(y, h + 2), h);
+        const u32* row = (const u32*)(src + (i64)r * im.pitch);
+        const u32 a = row[gl], c = row[gx], b = row[gr];
+        const u32 Lw = __builtin_amdgcn_perm(c, a, selL);
+        const u32 Cw = __builtin_amdgcn_perm(c, a, selC);
+        const u32 Rw = __builtin_amdgcn_perm(c, lastGroup ? a : b, selR);
+        // output j uses bytes j+1..j+4 (taps k0..k3) and j+5..j+7 (taps k2,k1,k0)
+        hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), W2,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), W1, 0u, false), false);
+        hs[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), W2,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), W1, 0u, false), false);
+        hs[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), W2,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), W1, 0u, false), false);
+        hs[3] = __builtin_amdgcn_udot4(Rw, W2, __builtin_amdgcn_udot4(Cw, W1, 0u, false), false);
+    };
+#pragma unroll
+    for (int i = 0; i < 6; i++) load_row(y0 - 3 + i, win[i]);
+    for (int yb = y0; yb < yEnd; yb += 7) {
+#pragma unroll
+        for (int ph = 0; ph < 7; ph++) {
+            const int y = yb + ph;
+            load_row(y + 3, win[(ph + 6) % 7]);
+            u32 out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 s = (u32)k0 * (win[ph % 7][k] + win[(ph + 6) % 7][k]) +
+                              (u32)k1 * (win[(ph + 1) % 7][k] + win[(ph + 5) % 7][k]) +
+                              (u32)k2 * (win[(ph + 2) % 7][k] + win[(ph + 4) % 7][k]) +
+                              (u32)k3 * win[(ph + 3) % 7][k];
+                u32 v = (s + 32768u) >> 16;
+                v = v > 255u ? 255u : v;
+                out |= v << (8 * k);
+            }
+            if (y < yEnd) *(u32*)(dst + (i64)y * L.blurPitch + 4 * gx) = out;
+        }
     }
 }
 
@@ -892,7 +987,7 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     g.w = w;
     g.h = hh;
     i64 pyrOff = 0, blurOff = 0;
-    int cellBase = 0, slotBase = 0, selBase = 0, tileBase = 0;
+    int cellBase = 0, slotBase = 0, selBase = 0, tileBase = 0, itemBase = 0;
     size_t maxLds = 0;
     for (int l = 0; l < g.nlevels; l++) {
         LevelGeom& L = g.lv[l];
@@ -915,6 +1010,10 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         L.blurTiles = L.blurTilesX * ((L.h + BLUR_TH - 1) / BLUR_TH);
         L.blurTileBase = tileBase;
         tileBase += L.blurTiles;
+        L.blurGroups = (L.w + 3) / 4;
+        L.blurBands = (L.h + BLUR_BH - 1) / BLUR_BH;
+        L.blurItemBase = itemBase;
+        itemBase += align_up(L.blurGroups * L.blurBands, 64);
         // reference src/ORBextractor.cc:781-797
         const float width = (float)((L.w - MIN_BORDER) - MIN_BORDER);
         const float height = (float)((L.h - MIN_BORDER) - MIN_BORDER);
@@ -967,6 +1066,7 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     g.totalSlots = std::max(slotBase, 1);
     g.totalSel = selBase;
     g.totalBlurTiles = tileBase;
+    g.totalBlurItems = itemBase;
     g.pyrFrameBytes = align_up((int)std::max<i64>(pyrOff, 64), 256);
     g.blurFrameBytes = align_up((int)blurOff, 256);
     if (maxLds > 160 * 1024 - 1024) {
@@ -1111,9 +1211,25 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     }
     {
         StageTimer t(h, ORBX_STAGE_BLUR);
-        dim3 grid(g.totalBlurTiles, n, 1), block(256, 1, 1);
-        hipLaunchKernelGGL(k_blur, grid, block, 0, st, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
-                           h->gaussK[1], h->gaussK[2], h->gaussK[3]);
+        // Level 0 is the caller's buffer: the streaming kernel reads it as aligned 32-bit
+        // words, so it needs 4-byte aligned rows and a width that is a multiple of 4.
+        const bool aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0 &&
+                              (g.w & 3) == 0 && img0.pitch >= g.w;
+        const int first = aligned0 ? 0 : 1;
+        if (!aligned0) {
+            dim3 grid(g.lv[0].blurTiles, n, 1), block(256, 1, 1);
+            hipLaunchKernelGGL(k_blur, grid, block, 0, st, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                               h->gaussK[1], h->gaussK[2], h->gaussK[3], 0);
+        }
+        const int itemBegin = g.lv[first].blurItemBase;
+        if (first < g.nlevels && g.totalBlurItems > itemBegin) {
+            // blockIdx.x counts from the first level's item base
+            Geom gs = g;
+            for (int l = first; l < g.nlevels; l++) gs.lv[l].blurItemBase -= itemBegin;
+            dim3 grid((g.totalBlurItems - itemBegin + 255) / 256, n, 1), block(256, 1, 1);
+            hipLaunchKernelGGL(k_blur_stream, grid, block, 0, st, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                               h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
+        }
     }
     {
         StageTimer t(h, ORBX_STAGE_DESCRIBE);
