@@ -56,6 +56,7 @@ struct LevelGeom {
 struct Geom {
     int nlevels, w, h;
     int totalCells, totalSlots, totalSel, totalBlurTiles, totalBlurItems;
+    int fastRoiPitch, fastPlaneOff, fastQueueOff, fastLdsBytes;  // k_fast LDS carve-up
     i64 pyrFrameBytes, blurFrameBytes;
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
@@ -293,15 +294,27 @@ __device__ __forceinline__ int fast_strength(const int* d) {
     return max(dark, -bright_neg);
 }
 
-// One wave per cell: ROI -> LDS, strength plane, NMS at iniTh, fallback to
-// minTh when nothing survives, survivors written in raster order to the
-// cell's slot range.
-__global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, const u8* __restrict__ pyr,
+// floor(i / d) for i, d < 65536 with magic = floor(2^32 / d) + 1 (d >= 2).
+__device__ __forceinline__ u32 fastdiv(u32 i, u32 d, u32 magic) { return d == 1 ? i : __umulhi(i, magic); }
+__device__ __forceinline__ u32 div_magic(u32 d) { return d <= 1 ? 0u : (u32)(0x100000000ull / d) + 1u; }
+
+// One wave per cell.  ROI -> LDS (aligned 32-bit loads), then a cascade:
+//   1. cheap necessary test on two opposite ring pairs at the lower threshold;
+//      survivors queued in raster order,
+//   2. full strength for queued pixels; pixels above the lower threshold are
+//      written to the strength plane and re-queued (still raster order),
+//   3. non-max suppression over the queue at iniTh, then at minTh when nothing
+//      survived (the reference's per-cell fallback), survivors written in
+//      raster order to the cell's slot range.
+// A single wave executes LDS operations in program order, so the phases need
+// no workgroup barrier beyond the compiler-level ordering of __syncthreads().
+__global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligned, const u8* __restrict__ pyr,
                                               u32* __restrict__ cellCount, u32* __restrict__ slots,
                                               int iniTh, int minTh) {
-    __shared__ u8 roi[ROI_MAX * ROI_MAX + 3];
-    __shared__ u8 plane[(MAX_CELL + 2) * (MAX_CELL + 2) + 2];
-    __shared__ u16 work[MAX_CELL * MAX_CELL];
+    extern __shared__ __align__(16) u8 lds[];
+    u8* roi = lds;
+    u8* plane = lds + g.fastPlaneOff;
+    u16* queue = (u16*)(lds + g.fastQueueOff);
     const int f = blockIdx.y;
     const int cell = blockIdx.x;
     int l = 0;
@@ -319,66 +332,91 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, const u8* __re
         if (lane == 0) *cnt = 0;
         return;
     }
+    const int RP = g.fastRoiPitch;
     const ImgRef im = level_image(g, l, img0, pyr);
-    const u8* src = im.base + (i64)f * im.frameStride + (i64)iniY * im.pitch + iniX;
-    for (int i = lane; i < rw * rh; i += 64) {
-        const int y = i / rw, x = i - y * rw;
-        roi[i] = src[(i64)y * im.pitch + x];
+    int xo = 0;
+    if (l > 0 || img0Aligned) {
+        const int xa = iniX & ~3;
+        xo = iniX - xa;
+        const int nW = (xo + rw + 3) >> 2;
+        const u32 mg = div_magic(nW);
+        const u8* srow = im.base + (i64)f * im.frameStride + (i64)iniY * im.pitch + xa;
+        for (int i = lane; i < nW * rh; i += 64) {
+            const int y = fastdiv(i, nW, mg), wd = i - y * nW;
+            ((u32*)(roi + y * RP))[wd] = *(const u32*)(srow + (i64)y * im.pitch + 4 * wd);
+        }
+    } else {
+        const u32 mg = div_magic(rw);
+        const u8* srow = im.base + (i64)f * im.frameStride + (i64)iniY * im.pitch + iniX;
+        for (int i = lane; i < rw * rh; i += 64) {
+            const int y = fastdiv(i, rw, mg), x = i - y * rw;
+            roi[y * RP + x] = srow[(i64)y * im.pitch + x];
+        }
     }
-    const int iw = rw - 6, ih = rh - 6, pw = iw + 2;
-    for (int i = lane; i < pw * (ih + 2); i += 64) plane[i] = 0;
+    const u8* R = roi + xo;
+    const int iw = rw - 6, ih = rh - 6, pw = iw + 2, npx = iw * ih;
+    const u32 mgw = div_magic(iw);
+    for (int i = lane; i < (pw * (ih + 2) + 3) / 4; i += 64) ((u32*)plane)[i] = 0;
     __syncthreads();
 
-    // Phase 1: cheap necessary test at the lower threshold on two opposite ring
-    // pairs per axis; survivors are queued for the full evaluation.
-    const int lowTh = min(iniTh, minTh);
-    int nwork = 0;
-    for (int base = 0; base < iw * ih; base += 64) {
+    const int lowTh = min(max(min(iniTh, minTh), 0), 255);
+    int n1 = 0;
+    for (int base = 0; base < npx; base += 64) {
         const int i = base + lane;
         bool pass = false;
-        if (i < iw * ih) {
-            const int y = i / iw, x = i - y * iw;
-            const u8* p = &roi[(y + 3) * rw + x + 3];
+        if (i < npx) {
+            const int y = fastdiv(i, iw, mgw), x = i - y * iw;
+            const u8* p = R + (y + 3) * RP + x + 3;
             const int v = p[0];
-            const int d0 = v - p[3 * rw], d8 = v - p[-3 * rw], d4 = v - p[3], d12 = v - p[-3];
-            const bool dk = (d0 > lowTh || d8 > lowTh) && (d4 > lowTh || d12 > lowTh);
-            const bool br = (d0 < -lowTh || d8 < -lowTh) && (d4 < -lowTh || d12 < -lowTh);
-            pass = dk || br;
+            const int d0 = v - p[3 * RP], d8 = v - p[-3 * RP], d4 = v - p[3], d12 = v - p[-3];
+            const int dk = min(max(d0, d8), max(d4, d12));
+            const int br = max(min(d0, d8), min(d4, d12));
+            pass = dk > lowTh || br < -lowTh;
         }
         int tot;
         const int off = wave_excl_count(pass, &tot);
-        if (pass) work[nwork + off] = (u16)i;
-        nwork += tot;
+        if (pass) queue[n1 + off] = (u16)i;
+        n1 += tot;
     }
     __syncthreads();
-    // Phase 2: full strength for queued pixels.
-    for (int base = 0; base < nwork; base += 64) {
+    int n2 = 0;
+    for (int base = 0; base < n1; base += 64) {
         const int wi = base + lane;
-        if (wi < nwork) {
-            const int i = work[wi];
-            const int y = i / iw, x = i - y * iw;
-            const u8* p = &roi[(y + 3) * rw + x + 3];
+        bool corner = false;
+        int i = 0;
+        if (wi < n1) {
+            i = queue[wi];
+            const int y = fastdiv(i, iw, mgw), x = i - y * iw;
+            const u8* p = R + (y + 3) * RP + x + 3;
             const int v = p[0];
             int d[16];
-            d[0] = v - p[3 * rw];
-            d[1] = v - p[3 * rw + 1];
-            d[2] = v - p[2 * rw + 2];
-            d[3] = v - p[rw + 3];
+            d[0] = v - p[3 * RP];
+            d[1] = v - p[3 * RP + 1];
+            d[2] = v - p[2 * RP + 2];
+            d[3] = v - p[RP + 3];
             d[4] = v - p[3];
-            d[5] = v - p[-rw + 3];
-            d[6] = v - p[-2 * rw + 2];
-            d[7] = v - p[-3 * rw + 1];
-            d[8] = v - p[-3 * rw];
-            d[9] = v - p[-3 * rw - 1];
-            d[10] = v - p[-2 * rw - 2];
-            d[11] = v - p[-rw - 3];
+            d[5] = v - p[-RP + 3];
+            d[6] = v - p[-2 * RP + 2];
+            d[7] = v - p[-3 * RP + 1];
+            d[8] = v - p[-3 * RP];
+            d[9] = v - p[-3 * RP - 1];
+            d[10] = v - p[-2 * RP - 2];
+            d[11] = v - p[-RP - 3];
             d[12] = v - p[-3];
-            d[13] = v - p[rw - 3];
-            d[14] = v - p[2 * rw - 2];
-            d[15] = v - p[3 * rw - 1];
+            d[13] = v - p[RP - 3];
+            d[14] = v - p[2 * RP - 2];
+            d[15] = v - p[3 * RP - 1];
             const int m = fast_strength(d);
-            plane[(y + 1) * pw + x + 1] = (u8)max(m, 0);
+            if (m > lowTh) {
+                corner = true;
+                plane[(y + 1) * pw + x + 1] = (u8)m;
+            }
         }
+        int tot;
+        const int off = wave_excl_count(corner, &tot);
+        __syncthreads();  // every lane has read its queue entry before the in-place compaction writes
+        if (corner) queue[n2 + off] = (u16)i;
+        n2 += tot;
     }
     __syncthreads();
 
@@ -386,14 +424,14 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, const u8* __re
     const int gx0 = cj * L.wCell + 3, gy0 = ci * L.hCell + 3;  // relative to the detection origin
     int total = 0;
     for (int pass = 0; pass < 2; pass++) {
-        int th = pass == 0 ? iniTh : minTh;
-        th = min(max(th, 0), 255);
-        for (int base = 0; base < iw * ih; base += 64) {
-            const int i = base + lane;
+        const int th = min(max(pass == 0 ? iniTh : minTh, 0), 255);
+        for (int base = 0; base < n2; base += 64) {
+            const int wi = base + lane;
             bool keep = false;
             int x = 0, y = 0, s = 0;
-            if (i < iw * ih) {
-                y = i / iw;
+            if (wi < n2) {
+                const int i = queue[wi];
+                y = fastdiv(i, iw, mgw);
                 x = i - y * iw;
                 const u8* q = &plane[(y + 1) * pw + x + 1];
                 const int m = q[0];
@@ -1067,6 +1105,18 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     g.totalSel = selBase;
     g.totalBlurTiles = tileBase;
     g.totalBlurItems = itemBase;
+    {
+        int mw = 1, mh = 1;
+        for (int l = 0; l < g.nlevels; l++)
+            if (g.lv[l].nCells > 0) {
+                mw = std::max(mw, g.lv[l].wCell);
+                mh = std::max(mh, g.lv[l].hCell);
+            }
+        g.fastRoiPitch = align_up(mw + 6 + 3, 4);
+        g.fastPlaneOff = align_up(g.fastRoiPitch * (mh + 6), 16);
+        g.fastQueueOff = g.fastPlaneOff + align_up((mw + 2) * (mh + 2) + 4, 16);
+        g.fastLdsBytes = g.fastQueueOff + align_up(2 * mw * mh, 16);
+    }
     g.pyrFrameBytes = align_up((int)std::max<i64>(pyrOff, 64), 256);
     g.blurFrameBytes = align_up((int)blurOff, 256);
     if (maxLds > 160 * 1024 - 1024) {
@@ -1199,9 +1249,10 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     }
     {
         StageTimer t(h, ORBX_STAGE_FAST);
+        const int aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0;
         dim3 grid(g.totalCells, n, 1), block(64, 1, 1);
-        hipLaunchKernelGGL(k_fast, grid, block, 0, st, g, img0, (const u8*)h->dPyr, h->dCellCount, h->dSlots,
-                           h->cfg.ini_th_fast, h->cfg.min_th_fast);
+        hipLaunchKernelGGL(k_fast, grid, block, g.fastLdsBytes, st, g, img0, aligned0, (const u8*)h->dPyr,
+                           h->dCellCount, h->dSlots, h->cfg.ini_th_fast, h->cfg.min_th_fast);
     }
     {
         StageTimer t(h, ORBX_STAGE_QUADTREE);
