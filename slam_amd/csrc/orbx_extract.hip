@@ -110,6 +110,71 @@ __global__ __launch_bounds__(256) void k_resize(ImgRef src, u8* dst, int dPitch,
     *(u32*)(dst + (i64)f * dFrame + (i64)y * dPitch + x0) = out;
 }
 
+#define RESIZE_BH 32  // destination rows per band of the streaming kernel
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// Streaming form of the same arithmetic.  A lane owns 4 destination columns
+// and walks down a band of rows; per source row it loads three aligned words
+// that cover its 4x2 taps, picks each pixel's two bytes with a per-lane byte
+// permutation fixed at start-up, and forms the horizontal sum with one
+// v_dot2_u32_u16.  Requires 4-byte aligned source rows and taps that fit the
+// three-word window (checked on the host; true for scale factors <= 2).
+__global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, u8* dst, int dPitch, i64 dFrame,
+                                                        int dw, int dh, const ResizeTap* __restrict__ xt,
+                                                        const ResizeTap* __restrict__ yt) {
+    const int G = (dw + 3) >> 2;
+    const int nb = (dh + RESIZE_BH - 1) / RESIZE_BH;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= G * nb) return;
+    const int band = item / G, gx = item - band * G;
+    const int f = blockIdx.y;
+    const ResizeTap t0 = xt[min(4 * gx, dw - 1)];
+    const int wb = t0.i0 >> 2;
+    u32 sel[4], coef[4];
+    bool hiPair[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const ResizeTap t = xt[min(4 * gx + j, dw - 1)];
+        const int o0 = t.i0 - 4 * wb, o1 = t.i1 - 4 * wb;
+        const int k = o0 >= 4 ? 1 : 0;
+        hiPair[j] = k != 0;
+        // bytes: [tap0, 0, tap1, 0]; selector 12 yields a zero byte
+        sel[j] = (u32)(o0 - 4 * k) | (12u << 8) | ((u32)(o1 - 4 * k) << 16) | (12u << 24);
+        coef[j] = (u32)(u16)t.c0 | ((u32)(u16)t.c1 << 16);
+    }
+    const int wA = min(wb, maxWord), wB = min(wb + 1, maxWord), wC = min(wb + 2, maxWord);
+    const u8* sbase = src.base + (i64)f * src.frameStride;
+    u8* dbase = dst + (i64)f * dFrame + 4 * gx;
+    const int y0 = band * RESIZE_BH, y1 = min(y0 + RESIZE_BH, dh);
+    auto hsum = [&](const u32* row, u32* t) {
+        const u32 A = row[wA], B = row[wB], C = row[wC];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 lo = hiPair[j] ? B : A, hi = hiPair[j] ? C : B;
+            const u32 pr = __builtin_amdgcn_perm(hi, lo, sel[j]);
+            u16x2 pv, cv;
+            __builtin_memcpy(&pv, &pr, 4);
+            __builtin_memcpy(&cv, &coef[j], 4);
+            t[j] = __builtin_amdgcn_udot2(pv, cv, 0u, false);
+        }
+    };
+    for (int y = y0; y < y1; y++) {
+        const ResizeTap ty = yt[y];
+        u32 ta[4], tb[4];
+        hsum((const u32*)(sbase + (i64)ty.i0 * src.pitch), ta);
+        hsum((const u32*)(sbase + (i64)ty.i1 * src.pitch), tb);
+        const u32 b0 = (u32)(int)ty.c0, b1 = (u32)(int)ty.c1;
+        u32 out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 v = (((b0 * (ta[j] >> 4)) >> 16) + ((b1 * (tb[j] >> 4)) >> 16) + 2u) >> 2;
+            out |= (v & 0xFFu) << (8 * j);
+        }
+        *(u32*)(dbase + (i64)y * dPitch) = out;
+    }
+}
+
 // ------------------------------------------------------------------ blur
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
@@ -935,6 +1000,7 @@ struct orbx_handle {
     ResizeTap* dTaps = nullptr;  // x taps then y taps for each level >= 1
     size_t tapsCap = 0;
     size_t tapXOff[ORBX_MAX_LEVELS], tapYOff[ORBX_MAX_LEVELS];
+    bool resizeStreamOk[ORBX_MAX_LEVELS];  // taps of a 4-pixel group fit the three-word window
     // scratch sized for scratchBatch frames of the current geometry
     int scratchBatch = 0;
     size_t scratchSig = 0;
@@ -1152,6 +1218,18 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
             t.c1 = (short)cv_round_host(fx * 2048);
             taps.push_back(t);
         }
+        {
+            bool ok = true;
+            const ResizeTap* xt = taps.data() + h->tapXOff[l];
+            for (int gx = 0; gx * 4 < dw; gx++) {
+                const int wb = xt[gx * 4].i0 >> 2;
+                for (int j = 0; j < 4; j++) {
+                    const ResizeTap& t = xt[std::min(gx * 4 + j, dw - 1)];
+                    if (t.i0 - 4 * wb > 7 || t.i1 - 4 * wb > 11 || t.i1 < t.i0 || t.i1 - t.i0 > 1) ok = false;
+                }
+            }
+            h->resizeStreamOk[l] = ok;
+        }
         h->tapYOff[l] = taps.size();
         for (int dy = 0; dy < dh; dy++) {
             float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -1242,9 +1320,18 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
                 src.pitch = g.lv[l - 1].pyrPitch;
             }
             const LevelGeom& L = g.lv[l];
-            dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, n), block(64, 4, 1);
-            hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, h->dPyr + L.pyrOff, L.pyrPitch,
-                               g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l], h->dTaps + h->tapYOff[l]);
+            const bool srcAligned = ((((uintptr_t)src.base) | (uintptr_t)src.pitch | (uintptr_t)src.frameStride) & 3u) == 0;
+            if (srcAligned && h->resizeStreamOk[l]) {
+                const int items = ((L.w + 3) / 4) * ((L.h + RESIZE_BH - 1) / RESIZE_BH);
+                dim3 grid((items + 255) / 256, n, 1), block(256, 1, 1);
+                hipLaunchKernelGGL(k_resize_stream, grid, block, 0, st, src, src.pitch / 4 - 1, h->dPyr + L.pyrOff,
+                                   L.pyrPitch, g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l],
+                                   h->dTaps + h->tapYOff[l]);
+            } else {
+                dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, n), block(64, 4, 1);
+                hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, h->dPyr + L.pyrOff, L.pyrPitch,
+                                   g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l], h->dTaps + h->tapYOff[l]);
+            }
         }
     }
     {
