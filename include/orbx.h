@@ -132,6 +132,10 @@ int orbx_profile_read(orbx_handle* h, float* ms, int* launches, int n);
 int orbx_profile_reset(orbx_handle* h);
 
 /* ---- debug taps used by the parity tests (stage outputs of the last pass) ---- */
+/* Device evaluation of the two float primitives of the descriptor path: the steering
+ * sine/cosine (radians) and fastAtan2 (degrees), n values each, host arrays. */
+int orbx_debug_sincos(orbx_handle* h, const float* angles, int n, float* sin_out, float* cos_out);
+int orbx_debug_atan2(orbx_handle* h, const float* y, const float* x, int n, float* out);
 /* Pyramid level image of frame `frame`: copies w*h bytes, tightly packed, to host dst. */
 int orbx_debug_level(orbx_handle* h, int frame, int level, uint8_t* dst);
 /* Blurred level image of frame `frame`: copies w*h bytes, tightly packed, to host dst. */

@@ -672,6 +672,12 @@ void oracle_level_size(const oracle_params* p, int w, int h, int level, int* lw,
 }
 
 int oracle_cv_round(double v) { return cv_round(v); }
+void oracle_sincosf(const float* a, int n, float* s, float* c) {
+    for (int i = 0; i < n; i++) {
+        s[i] = sinf(a[i]);
+        c[i] = cosf(a[i]);
+    }
+}
 float oracle_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 
 void oracle_resize_linear(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw,

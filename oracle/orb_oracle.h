@@ -47,6 +47,8 @@ void oracle_level_size(const oracle_params* p, int w, int h, int level, int* lw,
 
 /* ---- restated OpenCV primitives ---- */
 int oracle_cv_round(double v);
+/* host libm sinf/cosf, as the reference's descriptor code calls them */
+void oracle_sincosf(const float* a, int n, float* s, float* c);
 float oracle_fast_atan2(float y, float x);
 void oracle_resize_linear(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw,
                           int dh, size_t dstride);

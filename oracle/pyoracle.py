@@ -75,6 +75,13 @@ def cv_round(v):
     return lib().oracle_cv_round(float(v))
 
 
+def sincosf(angles):
+    a = np.ascontiguousarray(angles, np.float32)
+    s, c = np.zeros_like(a), np.zeros_like(a)
+    lib().oracle_sincosf(_p(a), len(a), _p(s), _p(c))
+    return s, c
+
+
 def fast_atan2(y, x):
     return lib().oracle_fast_atan2(float(y), float(x))
 

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, 
             t[j] = __builtin_amdgcn_udot2(pv, cv, 0u, false);
         }
     };
+#pragma unroll 4
     for (int y = y0; y < y1; y++) {
         const ResizeTap ty = yt[y];
         u32 ta[4], tb[4];
@@ -850,8 +851,17 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
 }
 
 // ------------------------------------------------------------------ describe
-__constant__ signed char c_pattern[ORBX_PATTERN_POINTS * 2];
-__constant__ signed char c_patch_uv[749 * 2];  // (u, v) of the circular patch, radius 15
+// Tables staged into LDS by every describe block (uploaded once at start-up):
+//   patch: 248 slots = 31 rows x 8 four-pixel words covering u in [-16, 15];
+//          per slot the byte weights (u + 15, or 0 outside the radius-15 disc)
+//          and the 0/1 membership bytes,
+//   pattern: the 256 rBRIEF tests, (x0, y0, x1, y1) as four signed bytes.
+struct DescribeTables {
+    u32 patchU[248];
+    u32 patchM[248];
+    u32 pattern[256];
+};
+__device__ DescribeTables d_tables;
 
 // cv::fastAtan2 restated: degrees in [0, 360), one rounding per operation.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
@@ -876,98 +886,176 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// Float sine/cosine of the descriptor steering angle.  Evaluated in double
-// precision and rounded once to float.
-__device__ __forceinline__ void steer_sincos(float angle, float* s, float* c) {
-    *s = (float)sin((double)angle);
-    *c = (float)cos((double)angle);
+// sinf/cosf of the steering angle, bit-identical to glibc 2.28+ for |x| < 120:
+// the same algorithm (double-precision range reduction by pi/2 and degree-7/8
+// minimax polynomials, one final rounding to float) with the same constants.
+// An exhaustive host check over every float in [0, 6.5] shows this evaluation
+// equals libm's result whether or not the products are fused.
+__device__ __forceinline__ float sincosf_poly(double x, double x2, double sgn, int n) {
+    // sgn = -1 selects the negated cosine table of quadrants 2 and 3
+    if ((n & 1) == 0) {
+        const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+        const double x3 = x * x2;
+        const double t1 = s2 + x2 * s3;
+        const double x7 = x3 * x2;
+        const double s = x + x3 * s1;
+        return (float)(s + x7 * t1);
+    } else {
+        const double c0 = 0x1p0 * sgn, c1 = -0x1.ffffffd0c621cp-2 * sgn, c2 = 0x1.55553e1068f19p-5 * sgn,
+                     c3 = -0x1.6c087e89a359dp-10 * sgn, c4 = 0x1.99343027bf8c3p-16 * sgn;
+        const double x4 = x2 * x2;
+        const double t2 = c3 + x2 * c4;
+        const double t1 = c1 + x2 * c2;
+        const double x6 = x4 * x2;
+        const double c = c0 + x2 * t1;
+        return (float)(c + x6 * t2);
+    }
 }
 
-// One wave per output keypoint slot: orientation on the level image, 256
-// steered tests on the blurred level, 28-byte keypoint + 32-byte descriptor.
+__device__ __forceinline__ void steer_sincos(float y, float* sn, float* cs) {
+    const u32 top = (__float_as_uint(y) >> 20) & 0x7ff;
+    const double x = (double)y;
+    if (top < ((__float_as_uint(0x1.921FB6p-1f) >> 20) & 0x7ff)) {
+        const double x2 = x * x;
+        if (top < ((__float_as_uint(0x1p-12f) >> 20) & 0x7ff)) {
+            *sn = y;
+            *cs = 1.0f;
+            return;
+        }
+        *sn = sincosf_poly(x, x2, 1.0, 0);
+        *cs = sincosf_poly(x, x2, 1.0, 1);
+        return;
+    }
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int)r + 0x800000) >> 24;
+    const double xr = x - (double)n * 0x1.921FB54442D18p0;
+    const double x2 = xr * xr;
+    // sine: sign[n & 3], table 1 when n & 2
+    {
+        const double sg = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        *sn = sincosf_poly(xr * sg, x2, (n & 2) ? -1.0 : 1.0, n);
+    }
+    // cosine: the same with n + 1 for the sign/table and n ^ 1 for the polynomial
+    {
+        const int m = n + 1;
+        const double sg = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
+        *cs = sincosf_poly(xr * sg, x2, (m & 2) ? -1.0 : 1.0, n ^ 1);
+    }
+}
+
+__global__ void k_debug_sincos(const float* in, float* sn, float* cs, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) steer_sincos(in[i], &sn[i], &cs[i]);
+}
+
+__global__ void k_debug_atan2(const float* y, const float* x, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fast_atan2_deg(y[i], x[i]);
+}
+
+#define DESC_KPW 4  // keypoints per wave
+
+// Orientation + descriptor.  Each wave handles DESC_KPW keypoint slots in turn.
+// Orientation: the radius-15 disc is read as 248 unaligned 32-bit words and
+// reduced with two v_dot4_u32_u8 per word (weights u+15 and membership).
+// Descriptor: 256 steered tests on the blurred level, one bit per lane and
+// round, gathered with wave ballots.
 __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8* __restrict__ pyr,
                                                    const u8* __restrict__ blur,
                                                    const u32* __restrict__ sel,
                                                    const int* __restrict__ selCount,
                                                    orbx_keypoint* kps, u8* desc, int cap, int* nOut,
                                                    int* errFlag) {
+    __shared__ DescribeTables T;
+    {
+        const u32* srcT = (const u32*)&d_tables;
+        u32* dstT = (u32*)&T;
+        for (int i = threadIdx.x; i < (int)(sizeof(DescribeTables) / 4); i += 256) dstT[i] = srcT[i];
+    }
+    __syncthreads();
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int* sc = selCount + (i64)f * ORBX_MAX_LEVELS;
-    int l = -1, idx = 0, total = 0;
-    for (int k = 0; k < g.nlevels; k++) {
-        const int c = sc[k];
-        if (l < 0 && s < total + c) {
-            l = k;
-            idx = s - total;
-        }
-        total += c;
-    }
-    if (s == 0 && lane == 0) {
+    int cum[ORBX_MAX_LEVELS + 1];
+    cum[0] = 0;
+#pragma unroll
+    for (int k = 0; k < ORBX_MAX_LEVELS; k++) cum[k + 1] = cum[k] + (k < g.nlevels ? sc[k] : 0);
+    const int total = cum[ORBX_MAX_LEVELS];
+    const int sBase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_KPW;
+    if (sBase == 0 && lane == 0) {
         nOut[f] = min(total, cap);
         if (total > cap) *errFlag = 2;
     }
-    if (l < 0 || s >= cap) return;
-    const LevelGeom& L = g.lv[l];
-    const u32 key = sel[(i64)f * g.totalSel + L.selBase + idx];
-    const int x = ORBX_PX(key), y = ORBX_PY(key);
-
-    const ImgRef im = level_image(g, l, img0, pyr);
-    const u8* center = im.base + (i64)f * im.frameStride + (i64)y * im.pitch + x;
-    int m10 = 0, m01 = 0;
-    for (int i = lane; i < 749; i += 64) {
-        const int u = c_patch_uv[2 * i], v = c_patch_uv[2 * i + 1];
-        const int val = center[(i64)v * im.pitch + u];
-        m10 += u * val;
-        m01 += v * val;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-    }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
     const float factorPI = (float)(M_PI / 180.f);
-    float a, b;
-    steer_sincos(__fmul_rn(angle, factorPI), &b, &a);
-    const u8* bc = blur + (i64)f * g.blurFrameBytes + L.blurOff + (i64)y * L.blurPitch + x;
-    u64 bits[4];
+    for (int kk = 0; kk < DESC_KPW; kk++) {
+        const int s = sBase + kk;
+        if (s >= total || s >= cap) return;
+        int l = 0;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int t = r * 64 + lane;
-        const float x0 = (float)c_pattern[4 * t], y0 = (float)c_pattern[4 * t + 1];
-        const float x1 = (float)c_pattern[4 * t + 2], y1 = (float)c_pattern[4 * t + 3];
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bc[(i64)r0 * L.blurPitch + c0];
-        const int t1 = bc[(i64)r1 * L.blurPitch + c1];
-        bits[r] = __ballot(t0 < t1);
-    }
-    const i64 o = (i64)f * cap + s;
-    if (lane < 4) {
-        const u64 v = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        u32* d = (u32*)(desc + o * 32 + lane * 8);
-        d[0] = (u32)v;
-        d[1] = (u32)(v >> 32);
-    }
-    if (lane == 0) {
-        orbx_keypoint k;
-        k.x = (float)x;
-        k.y = (float)y;
-        if (l != 0) {
-            k.x = __fmul_rn(k.x, L.scale);
-            k.y = __fmul_rn(k.y, L.scale);
+        for (int k = 1; k < ORBX_MAX_LEVELS; k++) l += (s >= cum[k]) ? 1 : 0;
+        l = min(l, g.nlevels - 1);
+        const int idx = s - cum[l];
+        const LevelGeom& L = g.lv[l];
+        const u32 key = sel[(i64)f * g.totalSel + L.selBase + idx];
+        const int x = ORBX_PX(key), y = ORBX_PY(key);
+
+        const ImgRef im = level_image(g, l, img0, pyr);
+        const u8* center = im.base + (i64)f * im.frameStride + (i64)y * im.pitch + x;
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int slot = lane + 64 * i;
+            if (slot < 248) {
+                const int v = (slot >> 3) - 15, u0 = (slot & 7) * 4 - 16;
+                u32 px;
+                __builtin_memcpy(&px, center + (i64)v * im.pitch + u0, 4);
+                const int D = (int)__builtin_amdgcn_udot4(px, T.patchU[slot], 0u, false);
+                const int S = (int)__builtin_amdgcn_udot4(px, T.patchM[slot], 0u, false);
+                m10 += D - 15 * S;
+                m01 += v * S;
+            }
         }
-        k.size = L.kpSize;
-        k.angle = angle;
-        k.response = (float)ORBX_PR(key);
-        k.octave = l;
-        k.class_id = -1;
-        kps[o] = k;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m10 += __shfl_xor(m10, o);
+            m01 += __shfl_xor(m01, o);
+        }
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        float a, b;
+        steer_sincos(__fmul_rn(angle, factorPI), &b, &a);
+        const u8* bc = blur + (i64)f * g.blurFrameBytes + L.blurOff + (i64)y * L.blurPitch + x;
+        u32 word = 0;  // lane k < 8 ends up holding descriptor bytes 4k..4k+3
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int pw = (int)T.pattern[r * 64 + lane];
+            const float x0 = (float)((pw << 24) >> 24), y0 = (float)((pw << 16) >> 24);
+            const float x1 = (float)((pw << 8) >> 24), y1 = (float)(pw >> 24);
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+            const int t0 = bc[r0 * L.blurPitch + c0];
+            const int t1 = bc[r1 * L.blurPitch + c1];
+            const u64 bits = __ballot(t0 < t1);
+            if (lane == 2 * r) word = (u32)bits;
+            if (lane == 2 * r + 1) word = (u32)(bits >> 32);
+        }
+        const i64 o = (i64)f * cap + s;
+        if (lane < 8) ((u32*)(desc + o * 32))[lane] = word;
+        // the 7 dwords of the 28-byte keypoint, one per lane
+        float kx = (float)x, ky = (float)y;
+        if (l != 0) {
+            kx = __fmul_rn(kx, L.scale);
+            ky = __fmul_rn(ky, L.scale);
+        }
+        u32 kv = __float_as_uint(kx);
+        kv = lane == 1 ? __float_as_uint(ky) : kv;
+        kv = lane == 2 ? __float_as_uint(L.kpSize) : kv;
+        kv = lane == 3 ? __float_as_uint(angle) : kv;
+        kv = lane == 4 ? __float_as_uint((float)ORBX_PR(key)) : kv;
+        kv = lane == 5 ? (u32)l : kv;
+        kv = lane == 6 ? 0xFFFFFFFFu : kv;
+        if (lane < 7) ((u32*)(kps + o))[lane] = kv;
     }
 }
 
@@ -1061,22 +1149,33 @@ void make_tables(orbx_handle* h) {
 int upload_constants() {
     // circular patch of radius 15 (reference src/ORBextractor.cc:450-465: umax)
     static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-    signed char uv[749 * 2];
-    int n = 0;
-    for (int v = -15; v <= 15; v++) {
-        const int d = umax[v < 0 ? -v : v];
-        for (int u = -d; u <= d; u++) {
-            uv[2 * n] = (signed char)u;
-            uv[2 * n + 1] = (signed char)v;
-            n++;
+    static DescribeTables t;
+    int inside = 0;
+    for (int slot = 0; slot < 248; slot++) {
+        const int v = (slot >> 3) - 15, u0 = (slot & 7) * 4 - 16;
+        u32 wu = 0, wm = 0;
+        for (int j = 0; j < 4; j++) {
+            const int u = u0 + j;
+            const int d = umax[v < 0 ? -v : v];
+            if (u >= -d && u <= d) {
+                wu |= (u32)(u + 15) << (8 * j);
+                wm |= 1u << (8 * j);
+                inside++;
+            }
         }
+        t.patchU[slot] = wu;
+        t.patchM[slot] = wm;
     }
-    if (n != 749) {
-        orbx_set_error("internal: patch has %d pixels", n);
+    if (inside != 749) {
+        orbx_set_error("internal: patch has %d pixels", inside);
         return ORBX_ERR_INVALID;
     }
-    ORBX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_patch_uv), uv, sizeof(uv)));
-    ORBX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ORBX_PATTERN_31, sizeof(ORBX_PATTERN_31)));
+    for (int i = 0; i < 256; i++) {
+        u32 w = 0;
+        for (int j = 0; j < 4; j++) w |= (u32)(u8)ORBX_PATTERN_31[4 * i + j] << (8 * j);
+        t.pattern[i] = w;
+    }
+    ORBX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_tables), &t, sizeof(t)));
     return ORBX_OK;
 }
 
@@ -1371,7 +1470,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     }
     {
         StageTimer t(h, ORBX_STAGE_DESCRIBE);
-        dim3 grid((std::min(cap, g.totalSel) + 3) / 4, n, 1), block(256, 1, 1);
+        dim3 grid((std::min(cap, g.totalSel) + 4 * DESC_KPW - 1) / (4 * DESC_KPW), n, 1), block(256, 1, 1);
         hipLaunchKernelGGL(k_describe, grid, block, 0, st, g, img0, (const u8*)h->dPyr, (const u8*)h->dBlur,
                            (const u32*)h->dSel, (const int*)h->dSelCount, dKps, dDesc, cap, dN, h->dErr);
     }
@@ -1646,6 +1745,40 @@ int orbx_profile_reset(orbx_handle* h) {
         h->prof.ms[s] = 0;
         h->prof.launches[s] = 0;
     }
+    return ORBX_OK;
+}
+
+int orbx_debug_sincos(orbx_handle* h, const float* angles, int n, float* sin_out, float* cos_out) {
+    if (!h || n < 0 || !angles || !sin_out || !cos_out) return ORBX_ERR_INVALID;
+    if (n == 0) return ORBX_OK;
+    float *d = nullptr;
+    ORBX_HIP_CHECK(hipMalloc((void**)&d, (size_t)n * 3 * sizeof(float)));
+    hipError_t e = hipMemcpy(d, angles, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_sincos, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const float*)d, d + n, d + 2 * (size_t)n, n);
+        e = hipStreamSynchronize(h->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(sin_out, d + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cos_out, d + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    ORBX_HIP_CHECK(e);
+    return ORBX_OK;
+}
+
+int orbx_debug_atan2(orbx_handle* h, const float* y, const float* x, int n, float* out) {
+    if (!h || n < 0 || !y || !x || !out) return ORBX_ERR_INVALID;
+    if (n == 0) return ORBX_OK;
+    float* d = nullptr;
+    ORBX_HIP_CHECK(hipMalloc((void**)&d, (size_t)n * 3 * sizeof(float)));
+    hipError_t e = hipMemcpy(d, y, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_atan2, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const float*)d, (const float*)(d + n), d + 2 * (size_t)n, n);
+        e = hipStreamSynchronize(h->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    ORBX_HIP_CHECK(e);
     return ORBX_OK;
 }
 

@@ -144,6 +144,19 @@ class ORBextractor:
         check(self._lib.orbx_profile_read(self._h, ms, ln, len(STAGES)))
         return {s: (ms[i], ln[i]) for i, s in enumerate(STAGES)}
 
+    def debug_sincos(self, angles):
+        a = np.ascontiguousarray(angles, np.float32)
+        sn, cs = np.zeros_like(a), np.zeros_like(a)
+        check(self._lib.orbx_debug_sincos(self._h, a.ctypes.data, len(a), sn.ctypes.data, cs.ctypes.data))
+        return sn, cs
+
+    def debug_atan2(self, y, x):
+        y = np.ascontiguousarray(y, np.float32)
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros_like(y)
+        check(self._lib.orbx_debug_atan2(self._h, y.ctypes.data, x.ctypes.data, len(y), out.ctypes.data))
+        return out
+
     def debug_blurred(self, frame, level):
         _, w, h, _ = self.level_info(frame, level)
         out = np.zeros((h, w), np.uint8)

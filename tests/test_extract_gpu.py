@@ -164,3 +164,29 @@ def test_too_large_image_is_rejected(extractor_vga):
     from slam_amd._lib import OrbxError
     with pytest.raises(OrbxError):
         extractor_vga(np.zeros((481, 640), np.uint8), None)
+
+
+def test_device_sincos_equals_host_libm(oracle, extractor_vga):
+    # every 257th float of [0, 2*pi] plus the angles the extractor can produce near quadrant edges
+    hi = np.float32(6.2832).view(np.uint32)
+    a = np.arange(0, int(hi), 257, dtype=np.uint32).view(np.float32)
+    extra = (np.arange(0, 360, 0.25, dtype=np.float32) * np.float32(np.pi / 180.0)).astype(np.float32)
+    a = np.concatenate([a, extra])
+    sn, cs = extractor_vga.debug_sincos(a)
+    rs, rc = oracle.sincosf(a)
+    assert np.array_equal(sn.view(np.uint32), rs.view(np.uint32))
+    assert np.array_equal(cs.view(np.uint32), rc.view(np.uint32))
+
+
+def test_device_fast_atan2_equals_oracle(oracle, extractor_vga):
+    rng = np.random.RandomState(0)
+    y = rng.randint(-200000, 200000, 200000).astype(np.float32)
+    x = rng.randint(-200000, 200000, 200000).astype(np.float32)
+    y[:1000] = 0
+    x[1000:2000] = 0
+    y[2000:2010] = 0
+    x[2000:2010] = 0
+    got = extractor_vga.debug_atan2(y, x)
+    ref = np.array([oracle.fast_atan2(float(a), float(b)) for a, b in zip(y[:20000], x[:20000])], np.float32)
+    assert np.array_equal(got[:20000].view(np.uint32), ref.view(np.uint32))
+    assert (got >= 0).all() and (got <= 360).all()
