@@ -78,9 +78,9 @@ def knn2_sharded(q_local, t_local, t_offset, local_knn2, merge=merge_partials, g
         dist.all_to_all_single(recv, mine, group=group)
     else:
         # gloo has no all-to-all: gather everything and keep this rank's slice
-        full = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(full, mine, group=group)
-        recv = full[:, rank].contiguous()
+        full = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(full, mine.reshape(-1), group=group)
+        recv = full.reshape(world, world, nq, 3)[:, rank].contiguous()
     acc = (recv[0, :, 0].contiguous(), recv[0, :, 1].contiguous(), recv[0, :, 2].contiguous())
     for r in range(1, world):
         part = (recv[r, :, 0].contiguous(), recv[r, :, 1].contiguous(), recv[r, :, 2].contiguous())

@@ -1,0 +1,128 @@
+"""Committed golden vectors (tests/golden, produced by make_golden.py from the oracle).
+
+CPU: the oracle still reproduces them (guards the checker itself).
+GPU: the HIP path reproduces them through the C ABI, without needing the oracle.
+"""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BOUNDS = (0.0, 0.0, 640.0, 480.0)
+FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
+
+
+def sha(a):
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def seeded_cases():
+    return sorted(f for f in glob.glob(os.path.join(G, "extract_*_s*.npz")))
+
+
+def load_image(z):
+    if "image" in z.files:
+        return z["image"]
+    img = synth.synth_image(int(z["w"]), int(z["h"]), int(z["seed"]))
+    assert sha(img) == str(z["image_sha1"]), "synthetic generator changed: regenerate the fixtures"
+    return img
+
+
+def same(k, d, z):
+    assert len(k) == len(z["kps"])
+    for f in FIELDS:
+        assert np.array_equal(k[f], z["kps"][f]), f
+    assert np.array_equal(d, z["desc"])
+
+
+def test_fixtures_exist():
+    assert len(seeded_cases()) >= 5
+    for f in ("extract_small_stored.npz", "extract_low_contrast.npz", "match_pair.npz"):
+        assert os.path.exists(os.path.join(G, f))
+
+
+@pytest.mark.parametrize("path", seeded_cases(), ids=os.path.basename)
+def test_oracle_reproduces_extraction(oracle, path):
+    z = np.load(path)
+    nf = int(z["nfeatures"])
+    k, d = oracle.extract(oracle.params(nfeatures=nf), load_image(z), cap=nf + 256)
+    same(k, d, z)
+
+
+def test_oracle_reproduces_edge_cases(oracle):
+    z = np.load(os.path.join(G, "extract_small_stored.npz"))
+    k, d = oracle.extract(oracle.params(nfeatures=int(z["nfeatures"])), z["image"], cap=600)
+    same(k, d, z)
+    z = np.load(os.path.join(G, "extract_low_contrast.npz"))
+    low = (synth.synth_image(640, 480, int(z["seed"])).astype(np.int32) // 12 + 100).astype(np.uint8)
+    assert sha(low) == str(z["image_sha1"])
+    k, d = oracle.extract(oracle.params(), low)
+    same(k, d, z)
+
+
+def test_oracle_reproduces_matching(oracle):
+    z = np.load(os.path.join(G, "match_pair.npz"))
+    fa = oracle.FrameData(z["ka"], z["da"], BOUNDS, z["sf"])
+    fb = oracle.FrameData(z["kb"], z["db"], BOUNDS, z["sf"])
+    n, m12, pm = oracle.search_for_initialization(fa, fb, z["prev"], 100, 0.9, True)
+    assert n == int(z["n_init"]) and np.array_equal(m12, z["m12"]) and np.array_equal(pm, z["pm"])
+    n, cl, co = oracle.search_by_projection_frames(fb, fa, z["valid"], z["u"], z["v"], z["invz"], z["has_obs"],
+                                                   z["ur"], 40.0, 15.0, 0, True)
+    assert n == int(z["n_proj"]) and np.array_equal(cl, z["claimed"]) and np.array_equal(co, z["claimed_obs"])
+    s, it = oracle.grid_build(fb)
+    assert np.array_equal(s, z["grid_start"]) and np.array_equal(it, z["grid_items"])
+    bi, bd, sd = oracle.knn2(z["knn_q"], z["knn_t"])
+    assert np.array_equal(bi, z["knn_idx"]) and np.array_equal(bd, z["knn_d"]) and np.array_equal(sd, z["knn_s"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", seeded_cases(), ids=os.path.basename)
+def test_hip_reproduces_extraction(path):
+    from slam_amd.extractor import ORBextractor
+    z = np.load(path)
+    img = load_image(z)
+    ex = ORBextractor(int(z["nfeatures"]), 1.2, 8, 20, 7, max_width=img.shape[1], max_height=img.shape[0])
+    try:
+        k, d = ex(img, None)
+        same(k, d, z)
+    finally:
+        ex.close()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_edge_cases():
+    from slam_amd.extractor import ORBextractor
+    z = np.load(os.path.join(G, "extract_small_stored.npz"))
+    ex = ORBextractor(int(z["nfeatures"]), 1.2, 8, 20, 7, max_width=200, max_height=150)
+    k, d = ex(z["image"], None)
+    same(k, d, z)
+    ex.close()
+    z = np.load(os.path.join(G, "extract_low_contrast.npz"))
+    low = (synth.synth_image(640, 480, int(z["seed"])).astype(np.int32) // 12 + 100).astype(np.uint8)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    k, d = ex(low, None)
+    same(k, d, z)
+    ex.close()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_matching():
+    from slam_amd.matcher import FrameView, ORBmatcher
+    z = np.load(os.path.join(G, "match_pair.npz"))
+    fa = FrameView(z["ka"], z["da"], BOUNDS, z["sf"])
+    fb = FrameView(z["kb"], z["db"], BOUNDS, z["sf"], u_right=z["ur"])
+    m = ORBmatcher(0.9, True)
+    n, m12, pm = m.SearchForInitialization(fa, fb, z["prev"], 100)
+    assert n == int(z["n_init"]) and np.array_equal(m12, z["m12"]) and np.array_equal(pm, z["pm"].reshape(-1, 2))
+    n, cl, co = m.SearchByProjection(fb, fa, 15.0, z["valid"], z["u"], z["v"], z["invz"], z["has_obs"], 40.0, 0)
+    assert n == int(z["n_proj"]) and np.array_equal(cl, z["claimed"]) and np.array_equal(co, z["claimed_obs"])
+    s, it = m.AssignFeaturesToGrid(fb)
+    assert np.array_equal(s, z["grid_start"]) and np.array_equal(it, z["grid_items"])
+    bi, bd, sd = m.knn2(z["knn_q"], z["knn_t"])
+    assert np.array_equal(bi, z["knn_idx"]) and np.array_equal(bd, z["knn_d"]) and np.array_equal(sd, z["knn_s"])
+    m.close()
