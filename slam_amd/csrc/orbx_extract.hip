@@ -425,72 +425,78 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
     for (int i = lane; i < (pw * (ih + 2) + 3) / 4; i += 64) ((u32*)plane)[i] = 0;
     __syncthreads();
 
-    const int lowTh = min(max(min(iniTh, minTh), 0), 255);
-    int n1 = 0;
-    for (int base = 0; base < npx; base += 64) {
-        const int i = base + lane;
-        bool pass = false;
-        if (i < npx) {
-            const int y = fastdiv(i, iw, mgw), x = i - y * iw;
-            const u8* p = R + (y + 3) * RP + x + 3;
-            const int v = p[0];
-            const int d0 = v - p[3 * RP], d8 = v - p[-3 * RP], d4 = v - p[3], d12 = v - p[-3];
-            const int dk = min(max(d0, d8), max(d4, d12));
-            const int br = max(min(d0, d8), min(d4, d12));
-            pass = dk > lowTh || br < -lowTh;
-        }
-        int tot;
-        const int off = wave_excl_count(pass, &tot);
-        if (pass) queue[n1 + off] = (u16)i;
-        n1 += tot;
-    }
-    __syncthreads();
-    int n2 = 0;
-    for (int base = 0; base < n1; base += 64) {
-        const int wi = base + lane;
-        bool corner = false;
-        int i = 0;
-        if (wi < n1) {
-            i = queue[wi];
-            const int y = fastdiv(i, iw, mgw), x = i - y * iw;
-            const u8* p = R + (y + 3) * RP + x + 3;
-            const int v = p[0];
-            int d[16];
-            d[0] = v - p[3 * RP];
-            d[1] = v - p[3 * RP + 1];
-            d[2] = v - p[2 * RP + 2];
-            d[3] = v - p[RP + 3];
-            d[4] = v - p[3];
-            d[5] = v - p[-RP + 3];
-            d[6] = v - p[-2 * RP + 2];
-            d[7] = v - p[-3 * RP + 1];
-            d[8] = v - p[-3 * RP];
-            d[9] = v - p[-3 * RP - 1];
-            d[10] = v - p[-2 * RP - 2];
-            d[11] = v - p[-RP - 3];
-            d[12] = v - p[-3];
-            d[13] = v - p[RP - 3];
-            d[14] = v - p[2 * RP - 2];
-            d[15] = v - p[3 * RP - 1];
-            const int m = fast_strength(d);
-            if (m > lowTh) {
-                corner = true;
-                plane[(y + 1) * pw + x + 1] = (u8)m;
-            }
-        }
-        int tot;
-        const int off = wave_excl_count(corner, &tot);
-        __syncthreads();  // every lane has read its queue entry before the in-place compaction writes
-        if (corner) queue[n2 + off] = (u16)i;
-        n2 += tot;
-    }
-    __syncthreads();
-
     u32* out = slots + (i64)f * g.totalSlots + L.slotBase + (i64)c * L.cellCap;
     const int gx0 = cj * L.wCell + 3, gy0 = ci * L.hCell + 3;  // relative to the detection origin
     int total = 0;
+    // The whole cascade runs at iniTh first: pixels whose strength is at most iniTh cannot
+    // influence that result.  Only a cell that ends with no survivor repeats it at minTh.
     for (int pass = 0; pass < 2; pass++) {
         const int th = min(max(pass == 0 ? iniTh : minTh, 0), 255);
+        if (pass == 1) {
+            for (int i = lane; i < (pw * (ih + 2) + 3) / 4; i += 64) ((u32*)plane)[i] = 0;
+            __syncthreads();
+        }
+        int n1 = 0;
+        for (int base = 0; base < npx; base += 64) {
+            const int i = base + lane;
+            bool pass1 = false;
+            if (i < npx) {
+                const int y = fastdiv(i, iw, mgw), x = i - y * iw;
+                const u8* p = R + (y + 3) * RP + x + 3;
+                const int v = p[0];
+                const int d0 = v - p[3 * RP], d8 = v - p[-3 * RP], d4 = v - p[3], d12 = v - p[-3];
+                const int dk = min(max(d0, d8), max(d4, d12));
+                const int br = max(min(d0, d8), min(d4, d12));
+                pass1 = dk > th || br < -th;
+            }
+            int tot;
+            const int off = wave_excl_count(pass1, &tot);
+            if (pass1) queue[n1 + off] = (u16)i;
+            n1 += tot;
+        }
+        __syncthreads();
+        int n2 = 0;
+        for (int base = 0; base < n1; base += 64) {
+            const int wi = base + lane;
+            bool corner = false;
+            int i = 0;
+            if (wi < n1) {
+                i = queue[wi];
+                const int y = fastdiv(i, iw, mgw), x = i - y * iw;
+                const u8* p = R + (y + 3) * RP + x + 3;
+                const int v = p[0];
+                int d[16];
+                d[0] = v - p[3 * RP];
+                d[1] = v - p[3 * RP + 1];
+                d[2] = v - p[2 * RP + 2];
+                d[3] = v - p[RP + 3];
+                d[4] = v - p[3];
+                d[5] = v - p[-RP + 3];
+                d[6] = v - p[-2 * RP + 2];
+                d[7] = v - p[-3 * RP + 1];
+                d[8] = v - p[-3 * RP];
+                d[9] = v - p[-3 * RP - 1];
+                d[10] = v - p[-2 * RP - 2];
+                d[11] = v - p[-RP - 3];
+                d[12] = v - p[-3];
+                d[13] = v - p[RP - 3];
+                d[14] = v - p[2 * RP - 2];
+                d[15] = v - p[3 * RP - 1];
+                const int m = fast_strength(d);
+                if (m > th) {
+                    corner = true;
+                    plane[(y + 1) * pw + x + 1] = (u8)m;
+                }
+            }
+            int tot;
+            const int off = wave_excl_count(corner, &tot);
+            __syncthreads();  // every lane has read its queue entry before the in-place compaction writes
+            if (corner) queue[n2 + off] = (u16)i;
+            n2 += tot;
+        }
+        __syncthreads();
+        // every plane entry is either 0 or a strength above th, so the response of a
+        // neighbour is simply max(strength - 1, 0)
         for (int base = 0; base < n2; base += 64) {
             const int wi = base + lane;
             bool keep = false;
@@ -500,14 +506,11 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                 y = fastdiv(i, iw, mgw);
                 x = i - y * iw;
                 const u8* q = &plane[(y + 1) * pw + x + 1];
-                const int m = q[0];
-                if (m > th) {
-                    s = m - 1;
-#define SC(o) ((int)q[o] > th ? (int)q[o] - 1 : 0)
-                    keep = s > SC(-1) && s > SC(1) && s > SC(-pw - 1) && s > SC(-pw) &&
-                           s > SC(-pw + 1) && s > SC(pw - 1) && s > SC(pw) && s > SC(pw + 1);
+                s = (int)q[0] - 1;
+#define SC(o) max((int)q[o] - 1, 0)
+                keep = s > SC(-1) && s > SC(1) && s > SC(-pw - 1) && s > SC(-pw) && s > SC(-pw + 1) &&
+                       s > SC(pw - 1) && s > SC(pw) && s > SC(pw + 1);
 #undef SC
-                }
             }
             int tot;
             const int off = wave_excl_count(keep, &tot);
