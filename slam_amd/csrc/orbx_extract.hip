@@ -125,10 +125,13 @@ __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, 
                                                         const ResizeTap* __restrict__ yt) {
     const int G = (dw + 3) >> 2;
     const int nb = (dh + RESIZE_BH - 1) / RESIZE_BH;
-    const int item = blockIdx.x * 256 + threadIdx.x;
+    // blockIdx.x is the frame: blocks are dealt round-robin over the 8 XCDs, so with a batch
+    // that is a multiple of 8 all blocks of one frame share an XCD (and its L2) and the rows
+    // two neighbouring bands both read are fetched from HBM once.
+    const int item = blockIdx.y * 256 + threadIdx.x;
     if (item >= G * nb) return;
     const int band = item / G, gx = item - band * G;
-    const int f = blockIdx.y;
+    const int f = blockIdx.x;
     const ResizeTap t0 = xt[min(4 * gx, dw - 1)];
     const int wb = t0.i0 >> 2;
     u32 sel[4], coef[4];
@@ -247,8 +250,8 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, ImgRef img0, const u8* __r
 __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const u8* __restrict__ pyr,
                                                       u8* __restrict__ blur, int k0, int k1, int k2, int k3,
                                                       int firstLevel) {
-    const int item = blockIdx.x * 256 + threadIdx.x;
-    const int f = blockIdx.y;
+    const int item = blockIdx.y * 256 + threadIdx.x;  // blockIdx.x = frame (one XCD per frame)
+    const int f = blockIdx.x;
     int l = firstLevel;
     while (l + 1 < g.nlevels && item >= g.lv[l + 1].blurItemBase) l++;
     const LevelGeom& L = g.lv[l];
@@ -381,8 +384,10 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
     u8* roi = lds;
     u8* plane = lds + g.fastPlaneOff;
     u16* queue = (u16*)(lds + g.fastQueueOff);
-    const int f = blockIdx.y;
-    const int cell = blockIdx.x;
+    // blockIdx.x = frame: with a batch that is a multiple of 8 all cells of a frame run on one
+    // XCD, so the halo rows and cache lines that neighbouring cells share come from its L2.
+    const int f = blockIdx.x;
+    const int cell = blockIdx.y;
     int l = 0;
     while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellBase) l++;
     const LevelGeom& L = g.lv[l];
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
         for (int i = threadIdx.x; i < (int)(sizeof(DescribeTables) / 4); i += 256) dstT[i] = srcT[i];
     }
     __syncthreads();
-    const int f = blockIdx.y;
+    const int f = blockIdx.x;  // frame first: one XCD per frame
     const int lane = threadIdx.x & 63;
     const int* sc = selCount + (i64)f * ORBX_MAX_LEVELS;
     int cum[ORBX_MAX_LEVELS + 1];
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
 #pragma unroll
     for (int k = 0; k < ORBX_MAX_LEVELS; k++) cum[k + 1] = cum[k] + (k < g.nlevels ? sc[k] : 0);
     const int total = cum[ORBX_MAX_LEVELS];
-    const int sBase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DESC_KPW;
+    const int sBase = (blockIdx.y * 4 + (threadIdx.x >> 6)) * DESC_KPW;
     if (sBase == 0 && lane == 0) {
         nOut[f] = min(total, cap);
         if (total > cap) *errFlag = 2;
@@ -1425,7 +1430,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             const bool srcAligned = ((((uintptr_t)src.base) | (uintptr_t)src.pitch | (uintptr_t)src.frameStride) & 3u) == 0;
             if (srcAligned && h->resizeStreamOk[l]) {
                 const int items = ((L.w + 3) / 4) * ((L.h + RESIZE_BH - 1) / RESIZE_BH);
-                dim3 grid((items + 255) / 256, n, 1), block(256, 1, 1);
+                dim3 grid(n, (items + 255) / 256, 1), block(256, 1, 1);
                 hipLaunchKernelGGL(k_resize_stream, grid, block, 0, st, src, src.pitch / 4 - 1, h->dPyr + L.pyrOff,
                                    L.pyrPitch, g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l],
                                    h->dTaps + h->tapYOff[l]);
@@ -1439,7 +1444,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     {
         StageTimer t(h, ORBX_STAGE_FAST);
         const int aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0;
-        dim3 grid(g.totalCells, n, 1), block(64, 1, 1);
+        dim3 grid(n, g.totalCells, 1), block(64, 1, 1);
         hipLaunchKernelGGL(k_fast, grid, block, g.fastLdsBytes, st, g, img0, aligned0, (const u8*)h->dPyr,
                            h->dCellCount, h->dSlots, h->cfg.ini_th_fast, h->cfg.min_th_fast);
     }
@@ -1466,14 +1471,14 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             // blockIdx.x counts from the first level's item base
             Geom gs = g;
             for (int l = first; l < g.nlevels; l++) gs.lv[l].blurItemBase -= itemBegin;
-            dim3 grid((g.totalBlurItems - itemBegin + 255) / 256, n, 1), block(256, 1, 1);
+            dim3 grid(n, (g.totalBlurItems - itemBegin + 255) / 256, 1), block(256, 1, 1);
             hipLaunchKernelGGL(k_blur_stream, grid, block, 0, st, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
                                h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
         }
     }
     {
         StageTimer t(h, ORBX_STAGE_DESCRIBE);
-        dim3 grid((std::min(cap, g.totalSel) + 4 * DESC_KPW - 1) / (4 * DESC_KPW), n, 1), block(256, 1, 1);
+        dim3 grid(n, (std::min(cap, g.totalSel) + 4 * DESC_KPW - 1) / (4 * DESC_KPW), 1), block(256, 1, 1);
         hipLaunchKernelGGL(k_describe, grid, block, 0, st, g, img0, (const u8*)h->dPyr, (const u8*)h->dBlur,
                            (const u32*)h->dSel, (const int*)h->dSelCount, dKps, dDesc, cap, dN, h->dErr);
     }

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output (tools/collect_profiles.sh) into small CSV/JSON summaries:
+only this library's kernels, per-kernel call count / average / total duration, and the
+HBM traffic per launch from the FETCH_SIZE and WRITE_SIZE passes.
+
+FETCH_SIZE on gfx950 reports half the bytes of a wide coalesced read stream, so the
+read side is doubled; WRITE_SIZE is taken as is.  Both are in KiB."""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = os.path.join("gpurun_out", "prof_" + tag)
+dst = sys.argv[2] if len(sys.argv) > 2 else src
+
+
+def short(name):
+    m = re.search(r"\bk_[a-z0-9_]+", name)
+    return m.group(0) if m else name
+
+
+def mine(name):
+    return "k_" in name and "at::native" not in name
+
+
+stats = collections.OrderedDict()
+p = os.path.join(src, "stats", "s_kernel_trace.csv")
+if os.path.exists(p):
+    per = collections.defaultdict(list)
+    meta = {}
+    for r in csv.DictReader(open(p)):
+        if not mine(r["Kernel_Name"]):
+            continue
+        k = short(r["Kernel_Name"])
+        per[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size_X"])
+    with open(os.path.join(dst, "kernel_stats_%s.csv" % tag), "w") as f:
+        f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,vgpr,sgpr,lds_bytes,workgroup\n")
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            f.write("%s,%d,%d,%.1f,%d,%d,%s,%s,%s,%s\n" % ((k, len(v), sum(v), sum(v) / len(v), min(v), max(v)) + meta[k]))
+            stats[k] = {"calls": len(v), "avg_ns": sum(v) / len(v)}
+
+traffic = {}
+for kind, sub, pre in (("FETCH_SIZE", "fetch", "f"), ("WRITE_SIZE", "write", "w")):
+    p = os.path.join(src, sub, pre + "_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        if r.get("Counter_Name") != kind or not mine(r["Kernel_Name"]):
+            continue
+        acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        # the first half of the launches are the warm-up step; all launches are identical in shape
+        traffic.setdefault(k, {})[kind + "_KiB_per_launch"] = sum(v) / len(v)
+        traffic[k]["launches_" + kind] = len(v)
+for k, t in traffic.items():
+    rd = t.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024.0 * 2.0
+    wr = t.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024.0
+    t["hbm_bytes_per_launch"] = rd + wr
+    t["read_bytes_corrected"] = rd
+    t["write_bytes"] = wr
+    t["frames_per_launch"] = 512
+json.dump({"tag": tag, "kernels": stats, "traffic": traffic}, open(os.path.join(dst, "summary_%s.json" % tag), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
