@@ -9,7 +9,7 @@
 // published generic C++ algorithms.  Everything else follows the reference
 // source line by line; each function cites the lines it restates.
 //
-// Build: g++ -O2 -ffp-contract=off (no FMA contraction: the reference's float
+// Build: g++ -O3 -ffp-contract=off (no FMA contraction: the reference's float
 // expressions are evaluated one rounding per operation).
 
 #include "orb_oracle.h"

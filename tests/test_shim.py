@@ -1,0 +1,49 @@
+"""The header-only C++ shim (include/orbx_shim.hpp): it compiles as plain C++ against
+the C ABI, and on a GPU its ORB_SLAM2::ORBextractor gives the same bytes as ctypes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "shim_check.cpp")
+LIBDIR = os.path.join(ROOT, "slam_amd")
+
+
+def build(tmp_path):
+    exe = os.path.join(str(tmp_path), "shim_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", exe, SRC, "-L" + LIBDIR, "-lorbx",
+                           "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    return exe
+
+
+def test_shim_compiles_and_fails_cleanly_without_gpu(tmp_path):
+    import torch
+    exe = build(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("no-device path only")
+    img = synth.synth_image(320, 240, 1)
+    raw = os.path.join(str(tmp_path), "i.raw")
+    img.tofile(raw)
+    r = subprocess.run([exe, raw, "320", "240", os.path.join(str(tmp_path), "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "orbx_create" in r.stderr
+
+
+@pytest.mark.gpu
+def test_shim_matches_ctypes(tmp_path, extractor_vga):
+    from slam_amd._lib import KP_DTYPE
+    exe = build(tmp_path)
+    img = synth.synth_image(640, 480, 17)
+    raw = os.path.join(str(tmp_path), "i.raw")
+    out = os.path.join(str(tmp_path), "o.bin")
+    img.tofile(raw)
+    subprocess.check_call([exe, raw, "640", "480", out])
+    blob = open(out, "rb").read()
+    n = int(np.frombuffer(blob[:4], np.int32)[0])
+    kps = np.frombuffer(blob[4:4 + 28 * n], KP_DTYPE)
+    desc = np.frombuffer(blob[4 + 28 * n:], np.uint8).reshape(n, 32)
+    k2, d2 = extractor_vga(img, None)
+    assert n == len(k2) and np.array_equal(kps, k2) and np.array_equal(desc, d2)
