@@ -77,6 +77,10 @@ void orbx_destroy(orbx_handle* h);
  * handle's own stream). */
 int orbx_set_stream(orbx_handle* h, void* hip_stream);
 int orbx_synchronize(orbx_handle* h);
+/* The blur of a pass depends only on the pyramid; by default it runs on a second
+ * stream beside FAST + quadtree and joins before the descriptor kernel.  on = 0
+ * serialises all kernels on the handle's stream (clean per-kernel timings). */
+int orbx_set_overlap(orbx_handle* h, int on);
 
 /* Upper bound on keypoints per frame (>= nfeatures; the quadtree may return a
  * few more than the quota per level, reference src/ORBextractor.cc:671-733). */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "orbx_destroy": (None, [_vp]),
     "orbx_set_stream": (_i, [_vp, _vp]),
     "orbx_synchronize": (_i, [_vp]),
+    "orbx_set_overlap": (_i, [_vp, _i]),
     "orbx_max_keypoints": (_i, [_vp]),
     "orbx_extract": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _i, C.POINTER(_i)]),
     "orbx_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _vp, _i, _vp, _i]),

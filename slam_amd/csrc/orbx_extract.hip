@@ -1084,6 +1084,11 @@ struct orbx_handle {
     int device = 0;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
+    // the blur of a pass only depends on the pyramid: it runs on a second stream beside
+    // FAST + quadtree and joins before the descriptor kernel
+    hipStream_t auxStream = nullptr;
+    hipEvent_t evPyramid = nullptr, evBlur = nullptr;
+    bool overlapBlur = true;
     // constructor tables
     float scale[ORBX_MAX_LEVELS], invScale[ORBX_MAX_LEVELS], sigma2[ORBX_MAX_LEVELS],
         invSigma2[ORBX_MAX_LEVELS];
@@ -1395,8 +1400,9 @@ int ensure_scratch(orbx_handle* h, int batch) {
 struct StageTimer {
     orbx_handle* h;
     int stage;
+    hipStream_t st;
     hipEvent_t stop = nullptr;
-    StageTimer(orbx_handle* h_, int stage_) : h(h_), stage(stage_) {
+    StageTimer(orbx_handle* h_, int stage_, hipStream_t st_ = nullptr) : h(h_), stage(stage_), st(st_ ? st_ : h_->stream) {
         if (!h->profiling) return;
         StageProfile& p = h->prof;
         if (p.used[stage] == p.ev[stage].size()) {
@@ -1405,11 +1411,11 @@ struct StageTimer {
             p.ev[stage].push_back(std::make_pair(a, b));
         }
         std::pair<hipEvent_t, hipEvent_t>& e = p.ev[stage][p.used[stage]++];
-        (void)hipEventRecord(e.first, h->stream);
+        (void)hipEventRecord(e.first, st);
         stop = e.second;
     }
     ~StageTimer() {
-        if (stop) (void)hipEventRecord(stop, h->stream);
+        if (stop) (void)hipEventRecord(stop, st);
     }
 };
 
@@ -1441,6 +1447,37 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             }
         }
     }
+    const bool fork = h->overlapBlur && h->auxStream != nullptr;
+    hipStream_t bst = fork ? h->auxStream : st;
+    if (fork) {
+        ORBX_HIP_CHECK(hipEventRecord(h->evPyramid, st));
+        ORBX_HIP_CHECK(hipStreamWaitEvent(h->auxStream, h->evPyramid, 0));
+    }
+    {
+        StageTimer t(h, ORBX_STAGE_BLUR, bst);
+        // Level 0 is the caller's buffer: the streaming kernel reads it as aligned 32-bit
+        // words, so it needs 4-byte aligned rows and a width that is a multiple of 4.
+        const bool aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0 &&
+                              (g.w & 3) == 0 && img0.pitch >= g.w;
+        const int first = aligned0 ? 0 : 1;
+        if (!aligned0) {
+            dim3 grid(g.lv[0].blurTiles, n, 1), block(256, 1, 1);
+            hipLaunchKernelGGL(k_blur, grid, block, 0, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                               h->gaussK[1], h->gaussK[2], h->gaussK[3], 0);
+        }
+        const int itemBegin = g.lv[first].blurItemBase;
+        if (first < g.nlevels && g.totalBlurItems > itemBegin) {
+            // blockIdx.x counts from the first level's item base
+            Geom gs = g;
+            for (int l = first; l < g.nlevels; l++) gs.lv[l].blurItemBase -= itemBegin;
+            dim3 grid(n, (g.totalBlurItems - itemBegin + 255) / 256, 1), block(256, 1, 1);
+            hipLaunchKernelGGL(k_blur_stream, grid, block, 0, bst, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                               h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
+        }
+    }
+    if (fork) {
+        ORBX_HIP_CHECK(hipEventRecord(h->evBlur, h->auxStream));
+    }
     {
         StageTimer t(h, ORBX_STAGE_FAST);
         const int aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0;
@@ -1454,28 +1491,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         hipLaunchKernelGGL(k_quadtree, grid, block, h->qtLds, st, g, (const u32*)h->dCellCount,
                            (const u32*)h->dSlots, h->dKeyPacked, h->dKeyNode, h->dSel, h->dSelCount, h->dErr);
     }
-    {
-        StageTimer t(h, ORBX_STAGE_BLUR);
-        // Level 0 is the caller's buffer: the streaming kernel reads it as aligned 32-bit
-        // words, so it needs 4-byte aligned rows and a width that is a multiple of 4.
-        const bool aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0 &&
-                              (g.w & 3) == 0 && img0.pitch >= g.w;
-        const int first = aligned0 ? 0 : 1;
-        if (!aligned0) {
-            dim3 grid(g.lv[0].blurTiles, n, 1), block(256, 1, 1);
-            hipLaunchKernelGGL(k_blur, grid, block, 0, st, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
-                               h->gaussK[1], h->gaussK[2], h->gaussK[3], 0);
-        }
-        const int itemBegin = g.lv[first].blurItemBase;
-        if (first < g.nlevels && g.totalBlurItems > itemBegin) {
-            // blockIdx.x counts from the first level's item base
-            Geom gs = g;
-            for (int l = first; l < g.nlevels; l++) gs.lv[l].blurItemBase -= itemBegin;
-            dim3 grid(n, (g.totalBlurItems - itemBegin + 255) / 256, 1), block(256, 1, 1);
-            hipLaunchKernelGGL(k_blur_stream, grid, block, 0, st, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
-                               h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
-        }
-    }
+    if (fork) ORBX_HIP_CHECK(hipStreamWaitEvent(st, h->evBlur, 0));
     {
         StageTimer t(h, ORBX_STAGE_DESCRIBE);
         dim3 grid(n, (std::min(cap, g.totalSel) + 4 * DESC_KPW - 1) / (4 * DESC_KPW), 1), block(256, 1, 1);
@@ -1534,6 +1550,12 @@ int orbx_create(const orbx_config* cfg, orbx_handle** out) {
         rc = ORBX_ERR_HIP;
     }
     h->stream = h->ownStream;
+    if (rc == ORBX_OK && (hipStreamCreateWithFlags(&h->auxStream, hipStreamNonBlocking) != hipSuccess ||
+                          hipEventCreateWithFlags(&h->evPyramid, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&h->evBlur, hipEventDisableTiming) != hipSuccess)) {
+        orbx_set_error("hipStreamCreate/hipEventCreate failed");
+        rc = ORBX_ERR_HIP;
+    }
     if (rc == ORBX_OK && (hipMalloc((void**)&h->dErr, sizeof(int)) != hipSuccess ||
                           hipMemset(h->dErr, 0, sizeof(int)) != hipSuccess)) {
         orbx_set_error("hipMalloc failed");
@@ -1562,6 +1584,12 @@ void orbx_destroy(orbx_handle* h) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
+    if (h->auxStream) {
+        (void)hipStreamSynchronize(h->auxStream);
+        (void)hipStreamDestroy(h->auxStream);
+    }
+    if (h->evPyramid) (void)hipEventDestroy(h->evPyramid);
+    if (h->evBlur) (void)hipEventDestroy(h->evBlur);
     if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
     delete h;
 }
@@ -1570,6 +1598,13 @@ int orbx_set_stream(orbx_handle* h, void* hip_stream) {
     if (!h) return ORBX_ERR_INVALID;
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->ownStream;
+    return ORBX_OK;
+}
+
+int orbx_set_overlap(orbx_handle* h, int on) {
+    if (!h) return ORBX_ERR_INVALID;
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->overlapBlur = on != 0;
     return ORBX_OK;
 }
 

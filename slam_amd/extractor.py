@@ -114,6 +114,9 @@ class ORBextractor:
     def set_stream(self, stream_ptr):
         check(self._lib.orbx_set_stream(self._h, C.c_void_p(stream_ptr)))
 
+    def set_overlap(self, on):
+        check(self._lib.orbx_set_overlap(self._h, int(bool(on))))
+
     def synchronize(self):
         check(self._lib.orbx_synchronize(self._h))
 
