@@ -201,22 +201,66 @@ int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const 
                                    float nn_ratio, int check_orientation, int* nmatches,
                                    int mem_space);
 
+/* ---- projected searches ----
+ * Every SearchByProjection variant of the reference has the same shape: the host projects
+ * map points into a frame (pose algebra stays in host C++), then per projected point the
+ * keypoints inside a window and level range are scanned in GetFeaturesInArea order for the
+ * closest descriptor, skipping keypoints that already hold a map point, and the winner is
+ * claimed immediately (so later queries see it).  orbm_search_projected is that shape;
+ * the variants differ only in how queries and policy are filled:
+ *
+ *   variant (reference src/ORBmatcher.cc)        radius                 levels            right gate  policy {claim, max_dist, ratio, ori}
+ *   (Frame&, vector<MapPoint*>&, th)   :62-155   r(viewCos)*th*s[lvl]   [lvl-1, lvl]      projXR      {0, TH_HIGH, 1, 0}
+ *   (Frame&, const Frame&, th, bMono)  :1533-1678 th*s[octave]          by motion         u-bf*invz   {0, TH_HIGH, 0, checkOri}
+ *   (Frame&, KeyFrame*, sFound, th, d) :1694-1836 th*s[lvl]             [lvl-1, lvl+1]    none        {1, d,       0, checkOri}
+ *   (KeyFrame*, Scw, pts, matched, th) :370-485   th*s[lvl]             [lvl-1, lvl]      none        {1, TH_LOW,  0, 0}
+ */
+typedef struct orbm_proj_queries {
+    int32_t n;
+    const uint8_t* valid;     /* n: 0 = skip this map point (bad, out of view, ...) */
+    const float* u;           /* n: projection */
+    const float* v;
+    const float* radius;      /* n: window half-size in pixels */
+    const int32_t* min_level; /* n: GetFeaturesInArea minLevel / maxLevel (-1 = open) */
+    const int32_t* max_level;
+    const uint8_t* desc;      /* n x 32: pMP->GetDescriptor() */
+    const float* angle;       /* n: keypoint angle for the rotation histogram (NULL if unused) */
+    const uint8_t* has_obs;   /* n: pMP->Observations() > 0 (NULL = all 1) */
+    const float* u_right;     /* n: projected right-image coordinate, or NULL for no stereo gate */
+    const float* right_gate;  /* n: candidates with mvuRight > 0 and |u_right - mvuRight| > gate are skipped */
+} orbm_proj_queries;
+
+typedef struct orbm_proj_policy {
+    int32_t claim_rule;        /* 0: skip keypoints whose map point has observations; 1: skip any keypoint holding a point */
+    int32_t max_dist;          /* accept best distance <= max_dist */
+    int32_t ratio_test;        /* 1: reject when best and second best share a level and best > nn_ratio * second */
+    float nn_ratio;
+    int32_t check_orientation; /* rotation histogram + ComputeThreeMaxima cull */
+} orbm_proj_policy;
+
+/* claimed (in/out, train->n): index of the query assigned to each train keypoint or -1
+ * (mvpMapPoints / vpMatched); claimed_obs (in/out): whether that holder has observations.
+ * query_best (out, n, may be NULL): train keypoint each query was assigned when it was
+ * processed, before the orientation cull, or -1.  *nmatches: the reference's return value. */
+int orbm_search_projected(orbm_context* m, const orbm_frame* train, const float* train_u_right,
+                          const orbm_proj_queries* q, const orbm_proj_policy* p, int32_t* claimed,
+                          uint8_t* claimed_obs, int32_t* query_best, int* nmatches, int mem_space);
+
 /* ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono)
- * (reference src/ORBmatcher.cc:1533-1678) from the point where each last-frame
- * map point has been projected into the current frame (:1577-1578): the
- * caller passes, per last-frame keypoint i, valid[i] (map point present and
- * not an outlier, :1564-1566), the projection u[i], v[i], inverse depth
- * invz[i], and has_obs[i] (pMP->Observations() > 0).  direction: 0 neither,
- * 1 forward, 2 backward (:1554-1556).  scale_factors: mvScaleFactors.
- * cur_claimed (in/out, n_cur ints): -1 = mvpMapPoints[i2] is NULL, else the
- * index of the last-frame point assigned; cur_claimed_obs (in/out): whether
- * that assigned point has observations (:1610-1612). */
+ * (reference src/ORBmatcher.cc:1533-1678; perfect/src/ORBmatcher.cc:1726 adds the lists of
+ * matched points, which are query_best in query order) from the point where each
+ * last-frame map point has been projected into the current frame (:1577-1578): per
+ * last-frame keypoint i the caller passes valid[i] (map point present and not an
+ * outlier, :1564-1566), u[i], v[i], invz[i], has_obs[i] and mp_desc (pMP->GetDescriptor(),
+ * n_last x 32; NULL = use last->desc).  direction: 0 neither, 1 forward, 2 backward
+ * (:1554-1556).  The checks of :1575-1582, the radius (:1591), the level window
+ * (:1593-1598) and the right-image gate (:1615-1621) are applied inside. */
 int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm_frame* last,
-                              const uint8_t* valid, const float* u, const float* v,
+                              const uint8_t* mp_desc, const uint8_t* valid, const float* u, const float* v,
                               const float* invz, const uint8_t* has_obs, const float* cur_u_right,
-                              const float* scale_factors, int nlevels, float bf, float th,
-                              int direction, int check_orientation, int32_t* cur_claimed,
-                              uint8_t* cur_claimed_obs, int* nmatches, int mem_space);
+                              const float* scale_factors, int nlevels, float bf, float th, int direction,
+                              int check_orientation, int32_t* cur_claimed, uint8_t* cur_claimed_obs,
+                              int32_t* query_best, int* nmatches, int mem_space);
 
 /* Brute-force 2-nearest-neighbour search over 256-bit descriptors with the
  * serial-scan semantics of the reference's descriptor loops

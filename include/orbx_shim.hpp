@@ -193,19 +193,41 @@ public:
 
     // reference src/ORBmatcher.cc:1533-1678.  The pose algebra (projection of each last-frame
     // map point, :1545-1578) stays with the caller: valid/u/v/invz/hasObs are per last-frame
-    // keypoint, direction is 0 (neither), 1 (forward) or 2 (backward).  claimed[i2] plays the
-    // role of CurrentFrame.mvpMapPoints[i2] (index of the last-frame point, or -1).
-    int SearchByProjection(const FrameView& CurrentFrame, const FrameView& LastFrame, float th, const unsigned char* valid,
-                           const float* u, const float* v, const float* invz, const unsigned char* hasObs, float bf,
-                           int direction, std::vector<int>& claimed, std::vector<unsigned char>& claimedObs) {
+    // keypoint, mpDesc holds pMP->GetDescriptor() per last-frame keypoint (N x 32, or null to
+    // use the last frame's own descriptors), direction is 0 (neither), 1 (forward) or
+    // 2 (backward).  claimed[i2] plays the role of CurrentFrame.mvpMapPoints[i2] (index of the
+    // last-frame point, or -1).  queryBest (optional) receives, per last-frame keypoint, the
+    // current keypoint it was assigned before the orientation cull: the matched point lists of
+    // perfect/src/ORBmatcher.cc:1835-1836 are its non-negative entries in order.
+    int SearchByProjection(const FrameView& CurrentFrame, const FrameView& LastFrame, float th, const unsigned char* mpDesc,
+                           const unsigned char* valid, const float* u, const float* v, const float* invz,
+                           const unsigned char* hasObs, float bf, int direction, std::vector<int>& claimed,
+                           std::vector<unsigned char>& claimedObs, std::vector<int>* queryBest = nullptr) {
         claimed.resize(CurrentFrame.N, -1);
         claimedObs.resize(CurrentFrame.N, 0);
+        if (queryBest) queryBest->assign(LastFrame.N, -1);
         int n = 0;
         orbm_frame c = CurrentFrame.c(), l = LastFrame.c();
-        orbx::check(orbm_search_by_projection(m_, &c, &l, valid, u, v, invz, hasObs, CurrentFrame.uRight,
+        orbx::check(orbm_search_by_projection(m_, &c, &l, mpDesc, valid, u, v, invz, hasObs, CurrentFrame.uRight,
                                               CurrentFrame.scaleFactors, CurrentFrame.nLevels, bf, th, direction,
-                                              mbCheckOrientation, claimed.data(), claimedObs.data(), &n, ORBX_MEM_HOST),
+                                              mbCheckOrientation, claimed.data(), claimedObs.data(),
+                                              queryBest ? queryBest->data() : nullptr, &n, ORBX_MEM_HOST),
                     "orbm_search_by_projection");
+        return n;
+    }
+
+    // The other projection searches (map points :62-155, keyframe :1694-1836, Sim3 :370-485)
+    // are orbm_search_projected with the query/policy rows listed in orbx.h.
+    int SearchProjected(const FrameView& train, const orbm_proj_queries& q, const orbm_proj_policy& p, std::vector<int>& claimed,
+                        std::vector<unsigned char>& claimedObs, std::vector<int>* queryBest = nullptr) {
+        claimed.resize(train.N, -1);
+        claimedObs.resize(train.N, 0);
+        if (queryBest) queryBest->assign(q.n, -1);
+        int n = 0;
+        orbm_frame t = train.c();
+        orbx::check(orbm_search_projected(m_, &t, train.uRight, &q, &p, claimed.data(), claimedObs.data(),
+                                          queryBest ? queryBest->data() : nullptr, &n, ORBX_MEM_HOST),
+                    "orbm_search_projected");
         return n;
     }
 

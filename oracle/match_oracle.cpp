@@ -255,13 +255,15 @@ int oracle_search_for_initialization(const oracle_frame* f1, const oracle_frame*
 
 // reference src/ORBmatcher.cc:1533-1678 from the point where the projection
 // (u, v, invzc) of each last-frame map point is known (:1577-1578).
-int oracle_search_by_projection_frames(const oracle_frame* cur, const oracle_frame* last,
+int oracle_search_by_projection_frames(const oracle_frame* cur, const oracle_frame* last, const uint8_t* mp_desc,
                                        const uint8_t* valid, const float* u_, const float* v_,
                                        const float* invz, const uint8_t* has_obs,
                                        const float* cur_u_right, float bf, float th,
                                        int direction, float nn_ratio, int check_orientation,
-                                       int* cur_claimed, uint8_t* cur_claimed_obs) {
+                                       int* cur_claimed, uint8_t* cur_claimed_obs, int* query_best) {
     (void)nn_ratio;
+    if (query_best)
+        for (int i = 0; i < last->n; i++) query_best[i] = -1;
     const oracle_frame& C = *cur;
     const oracle_frame& L = *last;
     Grid g = build_grid(C);
@@ -287,7 +289,7 @@ int oracle_search_by_projection_frames(const oracle_frame* cur, const oracle_fra
         else
             vIndices2 = features_in_area(C, g, u, v, radius, nLastOctave - 1, nLastOctave + 1);
         if (vIndices2.empty()) continue;
-        const uint8_t* dMP = L.desc + (size_t)i * 32;
+        const uint8_t* dMP = (mp_desc ? mp_desc : L.desc) + (size_t)i * 32;
         int bestDist = 256;
         int bestIdx2 = -1;
         for (int i2 : vIndices2) {
@@ -308,6 +310,7 @@ int oracle_search_by_projection_frames(const oracle_frame* cur, const oracle_fra
             cur_claimed[bestIdx2] = i;
             cur_claimed_obs[bestIdx2] = has_obs[i];
             nmatches++;
+            if (query_best) query_best[i] = bestIdx2;  // perfect/src/ORBmatcher.cc:1835-1836 pushes the pair here
             if (check_orientation) {
                 int bin = rot_bin(L.kps[i].angle, C.kps[bestIdx2].angle);
                 rotHist[bin].push_back(bestIdx2);
@@ -327,6 +330,156 @@ int oracle_search_by_projection_frames(const oracle_frame* cur, const oracle_fra
                     nmatches--;
                 }
             }
+        }
+    }
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:62-164: SearchByProjection(Frame&, const vector<MapPoint*>&, th).
+// Per map point: valid = mbTrackInView && !isBad(), the isInFrustum outputs, its descriptor
+// and whether it has observations.  claimed[] plays F.mvpMapPoints.
+int oracle_search_by_projection_mappoints(const oracle_frame* f, const float* f_u_right, int nmp,
+                                          const uint8_t* valid, const float* proj_x, const float* proj_y,
+                                          const float* proj_xr, const int* level, const float* view_cos,
+                                          const uint8_t* desc, const uint8_t* has_obs, float th, float nn_ratio,
+                                          int* claimed, uint8_t* claimed_obs) {
+    const oracle_frame& F = *f;
+    Grid g = build_grid(F);
+    int nmatches = 0;
+    const bool bFactor = th != 1.0;
+    for (int iMP = 0; iMP < nmp; iMP++) {
+        if (!valid[iMP]) continue;
+        const int nPredictedLevel = level[iMP];
+        float r = view_cos[iMP] > 0.998 ? 2.5 : 4.0;
+        if (bFactor) r *= th;
+        const std::vector<int> vIndices = features_in_area(F, g, proj_x[iMP], proj_y[iMP],
+                                                           r * F.scale_factors[nPredictedLevel],
+                                                           nPredictedLevel - 1, nPredictedLevel);
+        if (vIndices.empty()) continue;
+        const uint8_t* MPdescriptor = desc + (size_t)iMP * 32;
+        int bestDist = 256;
+        int bestLevel = -1;
+        int bestDist2 = 256;
+        int bestLevel2 = -1;
+        int bestIdx = -1;
+        for (int idx : vIndices) {
+            if (claimed[idx] >= 0)
+                if (claimed_obs[idx]) continue;
+            if (f_u_right[idx] > 0) {
+                const float er = fabs(proj_xr[iMP] - f_u_right[idx]);
+                if (er > r * F.scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = descriptor_distance(MPdescriptor, F.desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = F.kps[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = F.kps[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nn_ratio * bestDist2) continue;
+            claimed[bestIdx] = iMP;
+            claimed_obs[bestIdx] = has_obs[iMP];
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:1694-1836 from the point where the keyframe's map point i is
+// projected to (u, v) and its level predicted (:1730-1754).  valid folds :1715-1719 and the
+// distance check :1748.  claimed[] plays CurrentFrame.mvpMapPoints.
+int oracle_search_by_projection_keyframe(const oracle_frame* cur, int n, const uint8_t* valid, const float* u_,
+                                         const float* v_, const int* level, const uint8_t* desc,
+                                         const float* kf_angle, float th, int orb_dist, int check_orientation,
+                                         int* claimed) {
+    const oracle_frame& C = *cur;
+    Grid g = build_grid(C);
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for (int i = 0; i < n; i++) {
+        if (!valid[i]) continue;
+        const float u = u_[i], v = v_[i];
+        if (u < C.min_x || u > C.max_x) continue;
+        if (v < C.min_y || v > C.max_y) continue;
+        int nPredictedLevel = level[i];
+        const float radius = th * C.scale_factors[nPredictedLevel];
+        const std::vector<int> vIndices2 = features_in_area(C, g, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+        if (vIndices2.empty()) continue;
+        const uint8_t* dMP = desc + (size_t)i * 32;
+        int bestDist = 256;
+        int bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (claimed[i2] >= 0) continue;
+            const int dist = descriptor_distance(dMP, C.desc + (size_t)i2 * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= orb_dist) {
+            claimed[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                int bin = rot_bin(kf_angle[i], C.kps[bestIdx2].angle);
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i != ind1 && i != ind2 && i != ind3) {
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    claimed[rotHist[i][j]] = -1;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:370-485 from the point where candidate map point i is projected
+// with the similarity transform to (u, v) and its level predicted (:411-442).  valid folds
+// :403, :413, :434, :438.  matched[] plays vpMatched (index of the map point or -1).
+int oracle_search_by_projection_sim3(const oracle_frame* kf, int n, const uint8_t* valid, const float* u_,
+                                     const float* v_, const int* level, const uint8_t* desc, int th, int* matched) {
+    const oracle_frame& K = *kf;
+    Grid g = build_grid(K);
+    int nmatches = 0;
+    for (int iMP = 0; iMP < n; iMP++) {
+        if (!valid[iMP]) continue;
+        const float u = u_[iMP], v = v_[iMP];
+        if (!(u >= K.min_x && u < K.max_x && v >= K.min_y && v < K.max_y)) continue;  // KeyFrame::IsInImage
+        int nPredictedLevel = level[iMP];
+        const float radius = th * K.scale_factors[nPredictedLevel];
+        const std::vector<int> vIndices = features_in_area(K, g, u, v, radius);  // KeyFrame::GetFeaturesInArea: no levels
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = desc + (size_t)iMP * 32;
+        int bestDist = 256;
+        int bestIdx = -1;
+        for (int idx : vIndices) {
+            if (matched[idx] >= 0) continue;
+            const int kpLevel = K.kps[idx].octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            const int dist = descriptor_distance(dMP, K.desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        if (bestDist <= TH_LOW) {
+            matched[bestIdx] = iMP;
+            nmatches++;
         }
     }
     return nmatches;

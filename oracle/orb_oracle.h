@@ -113,12 +113,23 @@ int oracle_search_for_initialization(const oracle_frame* f1, const oracle_frame*
  * cur_claimed[] in/out: -1 free, otherwise index of the last-frame point held;
  * cur_claimed_obs[] in/out: whether that holder has observations.
  * u_right: mvuRight of the current frame.  direction: 0 neither, 1 forward, 2 backward. */
-int oracle_search_by_projection_frames(const oracle_frame* cur, const oracle_frame* last,
+int oracle_search_by_projection_frames(const oracle_frame* cur, const oracle_frame* last, const uint8_t* mp_desc,
                                        const uint8_t* valid, const float* u, const float* v,
                                        const float* invz, const uint8_t* has_obs,
                                        const float* cur_u_right, float bf, float th,
                                        int direction, float nn_ratio, int check_orientation,
-                                       int* cur_claimed, uint8_t* cur_claimed_obs);
+                                       int* cur_claimed, uint8_t* cur_claimed_obs, int* query_best);
+int oracle_search_by_projection_mappoints(const oracle_frame* f, const float* f_u_right, int nmp,
+                                          const uint8_t* valid, const float* proj_x, const float* proj_y,
+                                          const float* proj_xr, const int* level, const float* view_cos,
+                                          const uint8_t* desc, const uint8_t* has_obs, float th, float nn_ratio,
+                                          int* claimed, uint8_t* claimed_obs);
+int oracle_search_by_projection_keyframe(const oracle_frame* cur, int n, const uint8_t* valid, const float* u,
+                                         const float* v, const int* level, const uint8_t* desc,
+                                         const float* kf_angle, float th, int orb_dist, int check_orientation,
+                                         int* claimed);
+int oracle_search_by_projection_sim3(const oracle_frame* kf, int n, const uint8_t* valid, const float* u,
+                                     const float* v, const int* level, const uint8_t* desc, int th, int* matched);
 
 /* Brute-force 2-nearest search with the serial-scan semantics of the
  * reference's descriptor loops (src/ORBmatcher.cc:260-288): strict '<'

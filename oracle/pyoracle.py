@@ -240,20 +240,71 @@ def search_for_initialization(f1, f2, prev_matched, window_size=100, nn_ratio=0.
 
 
 def search_by_projection_frames(cur, last, valid, u, v, invz, has_obs, u_right, bf, th, direction,
-                                check_ori=True, claimed=None, claimed_obs=None):
+                                check_ori=True, claimed=None, claimed_obs=None, mp_desc=None,
+                                return_query_best=False):
     valid = np.ascontiguousarray(valid, np.uint8)
     u = np.ascontiguousarray(u, np.float32)
     v = np.ascontiguousarray(v, np.float32)
     invz = np.ascontiguousarray(invz, np.float32)
     has_obs = np.ascontiguousarray(has_obs, np.uint8)
     u_right = np.ascontiguousarray(u_right, np.float32)
+    md = None if mp_desc is None else np.ascontiguousarray(mp_desc, np.uint8)
     cl = np.full(max(cur.n, 1), -1, np.int32) if claimed is None else np.array(claimed, np.int32)
     co = np.zeros(max(cur.n, 1), np.uint8) if claimed_obs is None else np.array(claimed_obs, np.uint8)
+    qb = np.full(max(last.n, 1), -1, np.int32)
     n = lib().oracle_search_by_projection_frames(
-        C.byref(cur.c), C.byref(last.c), _p(valid), _p(u), _p(v), _p(invz), _p(has_obs),
-        _p(u_right), C.c_float(bf), C.c_float(th), int(direction), C.c_float(0.9),
-        int(bool(check_ori)), _p(cl), _p(co))
+        C.byref(cur.c), C.byref(last.c), _p(md) if md is not None else None, _p(valid), _p(u), _p(v),
+        _p(invz), _p(has_obs), _p(u_right), C.c_float(bf), C.c_float(th), int(direction),
+        C.c_float(0.9), int(bool(check_ori)), _p(cl), _p(co), _p(qb))
+    if return_query_best:
+        return n, cl[:cur.n].copy(), co[:cur.n].copy(), qb[:last.n].copy()
     return n, cl[:cur.n].copy(), co[:cur.n].copy()
+
+
+def search_by_projection_mappoints(f, f_u_right, valid, px, py, pxr, level, view_cos, desc, has_obs, th,
+                                   nn_ratio, claimed=None, claimed_obs=None):
+    valid = np.ascontiguousarray(valid, np.uint8)
+    px = np.ascontiguousarray(px, np.float32)
+    py = np.ascontiguousarray(py, np.float32)
+    pxr = np.ascontiguousarray(pxr, np.float32)
+    level = np.ascontiguousarray(level, np.int32)
+    view_cos = np.ascontiguousarray(view_cos, np.float32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    has_obs = np.ascontiguousarray(has_obs, np.uint8)
+    ur = np.ascontiguousarray(f_u_right, np.float32)
+    cl = np.full(max(f.n, 1), -1, np.int32) if claimed is None else np.array(claimed, np.int32)
+    co = np.zeros(max(f.n, 1), np.uint8) if claimed_obs is None else np.array(claimed_obs, np.uint8)
+    n = lib().oracle_search_by_projection_mappoints(
+        C.byref(f.c), _p(ur), len(px), _p(valid), _p(px), _p(py), _p(pxr), _p(level), _p(view_cos),
+        _p(desc), _p(has_obs), C.c_float(th), C.c_float(nn_ratio), _p(cl), _p(co))
+    return n, cl[:f.n].copy(), co[:f.n].copy()
+
+
+def search_by_projection_keyframe(cur, valid, u, v, level, desc, kf_angle, th, orb_dist, check_ori=True,
+                                  claimed=None):
+    valid = np.ascontiguousarray(valid, np.uint8)
+    u = np.ascontiguousarray(u, np.float32)
+    v = np.ascontiguousarray(v, np.float32)
+    level = np.ascontiguousarray(level, np.int32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    kf_angle = np.ascontiguousarray(kf_angle, np.float32)
+    cl = np.full(max(cur.n, 1), -1, np.int32) if claimed is None else np.array(claimed, np.int32)
+    n = lib().oracle_search_by_projection_keyframe(C.byref(cur.c), len(u), _p(valid), _p(u), _p(v), _p(level),
+                                                   _p(desc), _p(kf_angle), C.c_float(th), int(orb_dist),
+                                                   int(bool(check_ori)), _p(cl))
+    return n, cl[:cur.n].copy()
+
+
+def search_by_projection_sim3(kf, valid, u, v, level, desc, th, matched=None):
+    valid = np.ascontiguousarray(valid, np.uint8)
+    u = np.ascontiguousarray(u, np.float32)
+    v = np.ascontiguousarray(v, np.float32)
+    level = np.ascontiguousarray(level, np.int32)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    m = np.full(max(kf.n, 1), -1, np.int32) if matched is None else np.array(matched, np.int32)
+    n = lib().oracle_search_by_projection_sim3(C.byref(kf.c), len(u), _p(valid), _p(u), _p(v), _p(level),
+                                               _p(desc), int(th), _p(m))
+    return n, m[:kf.n].copy()
 
 
 def knn2(q, t):

@@ -29,6 +29,18 @@ class Config(C.Structure):
                 ("blur_variant", C.c_int32)]
 
 
+class ProjQueries(C.Structure):
+    _fields_ = [("n", C.c_int32), ("valid", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p),
+                ("radius", C.c_void_p), ("min_level", C.c_void_p), ("max_level", C.c_void_p),
+                ("desc", C.c_void_p), ("angle", C.c_void_p), ("has_obs", C.c_void_p),
+                ("u_right", C.c_void_p), ("right_gate", C.c_void_p)]
+
+
+class ProjPolicy(C.Structure):
+    _fields_ = [("claim_rule", C.c_int32), ("max_dist", C.c_int32), ("ratio_test", C.c_int32),
+                ("nn_ratio", C.c_float), ("check_orientation", C.c_int32)]
+
+
 class MFrame(C.Structure):
     _fields_ = [("kps", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int32), ("min_x", C.c_float),
                 ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
@@ -75,8 +87,10 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _i]),
     "orbm_search_for_initialization": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), _vp, _vp, _i,
                                             _f, _i, C.POINTER(_i), _i]),
-    "orbm_search_by_projection": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), _vp, _vp, _vp,
-                                       _vp, _vp, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp,
+    "orbm_search_projected": (_i, [_vp, C.POINTER(MFrame), _vp, C.POINTER(ProjQueries),
+                                   C.POINTER(ProjPolicy), _vp, _vp, _vp, C.POINTER(_i), _i]),
+    "orbm_search_by_projection": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), _vp, _vp, _vp, _vp,
+                                       _vp, _vp, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp, _vp,
                                        C.POINTER(_i), _i]),
     "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
     "orbm_knn2_merge": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),

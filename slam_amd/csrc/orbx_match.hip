@@ -256,68 +256,98 @@ __global__ __launch_bounds__(1024) void k_scan(const int* in, int* out, int n) {
     if (tid == 0) out[n] = carry;
 }
 
-// ------------------------------------------------------------------ SearchByProjection (frames)
-struct ProjArgs {
+// ------------------------------------------------------------------ projected searches
+// All SearchByProjection variants of the reference share one shape: per query (a map
+// point already projected into the train frame by the host) a window, a level range, an
+// optional right-image gate and a descriptor; then a scan of the candidates in
+// GetFeaturesInArea order under a claim rule, and (some variants) a rotation histogram.
+struct ProjQueries {
+    int n;
     const u8* valid;
-    const float *u, *v, *invz;
-    const u8* hasObs;
-    const float* curURight;
-    const float* scaleFactors;
-    float bf, th;
-    int direction;
+    const float *u, *v, *radius;
+    const int *minLevel, *maxLevel;
+    const u8* desc;         // n x 32, pMP->GetDescriptor()
+    const float* angle;     // for the rotation histogram; may be null
+    const u8* hasObs;       // pMP->Observations() > 0
+    const float* uRight;    // projected right coordinate for the stereo gate; may be null
+    const float* rightGate; // largest accepted |uRight - mvuRight[i2]|
 };
 
-__device__ __forceinline__ bool proj_query(const DevFrame& cur, const DevFrame& last, const ProjArgs& a, int i,
-                                           Query* q) {
-    // reference src/ORBmatcher.cc:1564-1598
-    if (!a.valid[i]) return false;
-    const float invzc = a.invz[i];
-    if (invzc < 0) return false;
-    const float u = a.u[i], v = a.v[i];
-    if (u < cur.minX || u > cur.maxX) return false;
-    if (v < cur.minY || v > cur.maxY) return false;
-    const int oct = last.kps[i].octave;
-    const float radius = __fmul_rn(a.th, a.scaleFactors[oct]);
-    q->x = u;
-    q->y = v;
-    q->r = radius;
-    if (a.direction == 1) {
-        q->minLevel = oct;
-        q->maxLevel = -1;
-    } else if (a.direction == 2) {
-        q->minLevel = 0;
-        q->maxLevel = oct;
-    } else {
-        q->minLevel = oct - 1;
-        q->maxLevel = oct + 1;
-    }
-    q->useRight = true;
-    q->ur = __fsub_rn(u, __fmul_rn(a.bf, invzc));
-    q->rGate = radius;
+struct ProjPolicy {
+    int claimRule;   // 0: skip train keypoints whose holder has observations; 1: skip any held keypoint
+    int maxDist;
+    int ratioTest;   // level-aware ratio test of SearchByProjection(Frame&, vector<MapPoint*>&)
+    float nnRatio;
+    int checkOri;
+};
+
+__device__ __forceinline__ bool projq_query(const ProjQueries& q, int i, Query* out) {
+    if (!q.valid[i]) return false;
+    out->x = q.u[i];
+    out->y = q.v[i];
+    out->r = q.radius[i];
+    out->minLevel = q.minLevel[i];
+    out->maxLevel = q.maxLevel[i];
+    out->useRight = q.uRight != nullptr;
+    out->ur = q.uRight ? q.uRight[i] : 0.f;
+    out->rGate = q.rightGate ? q.rightGate[i] : 0.f;
     return true;
 }
 
-// Candidate lists of every last-frame point (mode 0: counts; mode 2: CSR fill
-// with distances).  The right-image gate is state-free and applied here.
-__global__ __launch_bounds__(256) void k_proj_candidates(DevFrame cur, DevFrame last, const int* __restrict__ cellStart,
-                                                          const int* __restrict__ cellItems, ProjArgs a, int mode,
-                                                          const int* __restrict__ offs, int* candIdx, int* candDist,
-                                                          int* counts) {
+// Candidate lists of every query (mode 0: counts; mode 2: CSR fill with distances).
+// The right-image gate is state-free and applied here.
+__global__ __launch_bounds__(256) void k_projq_candidates(DevFrame train, const int* __restrict__ cellStart,
+                                                           const int* __restrict__ cellItems,
+                                                           const float* __restrict__ trainURight, ProjQueries q, int mode,
+                                                           const int* __restrict__ offs, int* candIdx, int* candDist,
+                                                           int* counts) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= last.n) return;
-    Query q;
+    if (i >= q.n) return;
+    Query qq;
     int n = 0;
-    if (proj_query(cur, last, a, i, &q)) {
-        const u8* qd = last.desc + (i64)i * 32;
+    if (projq_query(q, i, &qq)) {
+        const u8* qd = q.desc + (i64)i * 32;
         const i64 rowBase = mode == 2 ? offs[i] : 0;
-        n = walk_window(cur, cellStart, cellItems, a.curURight, q, [&](int pos, int idx) {
+        n = walk_window(train, cellStart, cellItems, trainURight, qq, [&](int pos, int idx) {
             if (mode == 2) {
                 candIdx[rowBase + pos] = idx;
-                candDist[rowBase + pos] = desc_distance(qd, cur.desc + (i64)idx * 32);
+                candDist[rowBase + pos] = desc_distance(qd, train.desc + (i64)idx * 32);
             }
         });
     }
     if ((threadIdx.x & 63) == 0 && mode == 0) counts[i] = n;
+}
+
+// Per-query inputs of SearchByProjection(cur, last): reference src/ORBmatcher.cc:1564-1598,
+// 1615-1621.  One thread per last-frame keypoint.
+__global__ void k_m4_queries(DevFrame cur, DevFrame last, const u8* valid, const float* u, const float* v,
+                             const float* invz, const float* scaleFactors, float bf, float th, int direction,
+                             u8* qValid, float* qRadius, int* qMin, int* qMax, float* qAngle, float* qUR) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= last.n) return;
+    bool ok = valid[i] != 0;
+    const float invzc = invz[i];
+    if (invzc < 0) ok = false;
+    const float uu = u[i], vv = v[i];
+    if (uu < cur.minX || uu > cur.maxX) ok = false;
+    if (vv < cur.minY || vv > cur.maxY) ok = false;
+    const orbx_keypoint kp = last.kps[i];
+    const int oct = kp.octave;
+    const float radius = __fmul_rn(th, scaleFactors[oct]);
+    qValid[i] = ok ? 1 : 0;
+    qRadius[i] = radius;
+    if (direction == 1) {
+        qMin[i] = oct;
+        qMax[i] = -1;
+    } else if (direction == 2) {
+        qMin[i] = 0;
+        qMax[i] = oct;
+    } else {
+        qMin[i] = oct - 1;
+        qMax[i] = oct + 1;
+    }
+    qAngle[i] = kp.angle;
+    qUR[i] = __fsub_rn(uu, __fmul_rn(bf, invzc));
 }
 
 // reference src/ORBmatcher.cc:1849-1894
@@ -370,41 +400,74 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
     return v;
 }
 
-// Sequential part of SearchByProjection(cur, last): queries in index order,
-// candidates of one query spread over the 64 lanes.  One wave.
-__global__ __launch_bounds__(64) void k_proj_resolve(DevFrame cur, DevFrame last, ProjArgs a,
-                                                       const int* __restrict__ offs, const int* __restrict__ candIdx,
-                                                       const int* __restrict__ candDist, int checkOri, int* claimed,
-                                                       u8* claimedObs, int* qBest, int* qBin, int* nmatchesOut) {
+// Sequential part of the projected searches: queries in index order, candidates of one
+// query spread over the 64 lanes.  One wave.  Best = first minimum among admissible
+// candidates (strict '<' scan starting at 256).  With ratioTest the second-best distance
+// and the pyramid level of the keypoint holding it are reproduced as the sequential scan
+// leaves them: when the final best arrives the previous best becomes second; afterwards
+// only a strictly smaller distance replaces it.
+__global__ __launch_bounds__(64) void k_projq_resolve(DevFrame train, ProjQueries q, ProjPolicy pol,
+                                                        const int* __restrict__ offs, const int* __restrict__ candIdx,
+                                                        const int* __restrict__ candDist, int* claimed, u8* claimedObs,
+                                                        int* qBest, int* qBin, int* nmatchesOut) {
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int keep[3];
     const int lane = threadIdx.x;
     if (lane < HISTO_LENGTH) hist[lane] = 0;
     __syncthreads();
     int nmatches = 0;
-    for (int i = 0; i < last.n; i++) {
+    for (int i = 0; i < q.n; i++) {
         const int b = offs[i], e = offs[i + 1];
         int best = -1;
         if (e > b) {
             u64 key = ~0ull;
             for (int k = b + lane; k < e; k += 64) {
                 const int i2 = candIdx[k];
-                if (claimed[i2] >= 0 && claimedObs[i2]) continue;
+                const bool held = claimed[i2] >= 0 && (pol.claimRule == 1 || claimedObs[i2]);
+                if (held) continue;
                 const u64 kk = ((u64)(u32)candDist[k] << 32) | (u32)(k - b);
                 key = kk < key ? kk : key;
             }
             key = wave_min_u64(key);
-            // bestDist starts at 256 and only strictly smaller distances replace it
-            if (key != ~0ull && (int)(key >> 32) < 256 && (int)(key >> 32) <= TH_HIGH)
-                best = candIdx[b + (int)(key & 0xFFFFFFFFu)];
+            const int bestDist = (int)(key >> 32);
+            if (key != ~0ull && bestDist < 256 && bestDist <= pol.maxDist) {
+                const int bestPos = (int)(key & 0xFFFFFFFFu);
+                best = candIdx[b + bestPos];
+                if (pol.ratioTest) {
+                    u64 kp = ~0ull, kq = ~0ull;  // first minimum before / after the best
+                    for (int k = b + lane; k < e; k += 64) {
+                        const int pos = k - b;
+                        if (pos == bestPos) continue;
+                        const int i2 = candIdx[k];
+                        const bool held = claimed[i2] >= 0 && (pol.claimRule == 1 || claimedObs[i2]);
+                        if (held) continue;
+                        const u64 kk = ((u64)(u32)candDist[k] << 32) | (u32)pos;
+                        if (pos < bestPos) kp = kk < kp ? kk : kp;
+                        else kq = kk < kq ? kk : kq;
+                    }
+                    kp = wave_min_u64(kp);
+                    kq = wave_min_u64(kq);
+                    int second = 256, level2 = -1;
+                    if (kp != ~0ull && (int)(kp >> 32) < 256) {
+                        second = (int)(kp >> 32);
+                        level2 = train.kps[candIdx[b + (int)(kp & 0xFFFFFFFFu)]].octave;
+                    }
+                    if (kq != ~0ull && (int)(kq >> 32) < second) {
+                        second = (int)(kq >> 32);
+                        level2 = train.kps[candIdx[b + (int)(kq & 0xFFFFFFFFu)]].octave;
+                    }
+                    const int level = train.kps[best].octave;
+                    if (level == level2 && (float)bestDist > __fmul_rn(pol.nnRatio, (float)second)) best = -1;
+                }
+            }
         }
         int bin = -1;
         if (best >= 0) {
             nmatches++;
-            if (checkOri) bin = rot_bin(last.kps[i].angle, cur.kps[best].angle);
+            if (pol.checkOri) bin = rot_bin(q.angle[i], train.kps[best].angle);
             if (lane == 0) {
                 claimed[best] = i;
-                claimedObs[best] = a.hasObs[i];
+                claimedObs[best] = q.hasObs ? q.hasObs[i] : 1;
                 if (bin >= 0) hist[bin]++;
             }
             __threadfence_block();
@@ -415,7 +478,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(DevFrame cur, DevFrame last
         }
     }
     __syncthreads();
-    if (checkOri) {
+    if (pol.checkOri) {
         if (lane == 0) {
             int i1 = -1, i2 = -1, i3 = -1;
             three_maxima(hist, HISTO_LENGTH, i1, i2, i3);
@@ -425,7 +488,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(DevFrame cur, DevFrame last
         }
         __syncthreads();
         int removed = 0;
-        for (int i = lane; i < last.n; i += 64) {
+        for (int i = lane; i < q.n; i += 64) {
             const int bin = qBin[i];
             if (bin >= 0 && bin != keep[0] && bin != keep[1] && bin != keep[2]) {
                 claimed[qBest[i]] = -1;
@@ -923,11 +986,107 @@ int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const 
     return ORBX_OK;
 }
 
-int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm_frame* last, const uint8_t* valid,
-                              const float* u, const float* v, const float* invz, const uint8_t* has_obs,
-                              const float* cur_u_right, const float* scale_factors, int nlevels, float bf, float th,
-                              int direction, int check_orientation, int32_t* cur_claimed, uint8_t* cur_claimed_obs,
-                              int* nmatches, int mem_space) {
+// Shared host part: grid of the train frame, candidate CSR, sequential resolve.
+static int run_projected(orbm_context* m, const DevFrame& train, const float* dTrainURight, const ProjQueries& q,
+                         const ProjPolicy& pol, int32_t* claimed, uint8_t* claimed_obs, int32_t* query_best, int* nmatches,
+                         int mem_space) {
+    int rc;
+    const int nq = q.n, nt = train.n;
+    *nmatches = 0;
+    if (nq == 0 || nt == 0) {
+        if (query_best && nq > 0) {
+            if (mem_space == ORBX_MEM_DEVICE) ORBX_HIP_CHECK(hipMemsetAsync(query_best, 0xFF, (size_t)nq * 4, m->stream));
+            else for (int i = 0; i < nq; i++) query_best[i] = -1;
+        }
+        return ORBX_OK;
+    }
+    int *cs, *ci;
+    if ((rc = build_grid(m, train, &cs, &ci))) return rc;
+    void *cnt, *offs, *qn, *scal;
+    if ((rc = pool_get(m, SL_COUNTS, (size_t)nq * 4, &cnt)) || (rc = pool_get(m, SL_OFFS, (size_t)(nq + 1) * 4, &offs)) ||
+        (rc = pool_get(m, SL_STATE_D, (size_t)nq * 4, &qn)) || (rc = pool_get(m, SL_SCALAR, 64, &scal)))
+        return rc;
+    hipLaunchKernelGGL(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
+                       dTrainURight, q, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, nq);
+    int total = 0;
+    ORBX_HIP_CHECK(hipMemcpyAsync(&total, (int*)offs + nq, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    void *cIdx, *cDist;
+    if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
+        (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
+        return rc;
+    hipLaunchKernelGGL(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
+                       dTrainURight, q, 2, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr);
+    int* dClaim;
+    u8* dClaimObs;
+    int* dQBest;
+    if (mem_space == ORBX_MEM_DEVICE) {
+        dClaim = (int*)claimed;
+        dClaimObs = claimed_obs;
+    } else {
+        void *p1, *p2;
+        if ((rc = pool_get(m, SL_STATE_A, (size_t)nt * 4, &p1)) || (rc = pool_get(m, SL_STATE_B, (size_t)nt, &p2))) return rc;
+        dClaim = (int*)p1;
+        dClaimObs = (u8*)p2;
+        ORBX_HIP_CHECK(hipMemcpyAsync(dClaim, claimed, (size_t)nt * 4, hipMemcpyHostToDevice, m->stream));
+        ORBX_HIP_CHECK(hipMemcpyAsync(dClaimObs, claimed_obs, (size_t)nt, hipMemcpyHostToDevice, m->stream));
+    }
+    if (mem_space == ORBX_MEM_DEVICE && query_best) {
+        dQBest = (int*)query_best;
+    } else {
+        void* p3;
+        if ((rc = pool_get(m, SL_STATE_C, (size_t)nq * 4, &p3))) return rc;
+        dQBest = (int*)p3;
+    }
+    hipLaunchKernelGGL(k_projq_resolve, dim3(1), dim3(64), 0, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
+                       (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)claimed, (const int*)dClaim, (size_t)nt, mem_space))) return rc;
+    if ((rc = copy_back(m, claimed_obs, (const u8*)dClaimObs, (size_t)nt, mem_space))) return rc;
+    if (query_best && (rc = copy_back(m, (int*)query_best, (const int*)dQBest, (size_t)nq, mem_space))) return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, scal, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_search_projected(orbm_context* m, const orbm_frame* train, const float* train_u_right,
+                          const orbm_proj_queries* q, const orbm_proj_policy* p, int32_t* claimed, uint8_t* claimed_obs,
+                          int32_t* query_best, int* nmatches, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (!q || !p || !claimed || !claimed_obs || !nmatches || q->n < 0 ||
+        (q->n > 0 && (!q->valid || !q->u || !q->v || !q->radius || !q->min_level || !q->max_level || !q->desc)) ||
+        (p->check_orientation && q->n > 0 && !q->angle) || (q->u_right && !q->right_gate) || (q->u_right && !train_u_right)) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    DevFrame dt;
+    if ((rc = make_frame(m, train, SL_F2_KPS, SL_F2_DESC, mem_space, &dt))) return rc;
+    const size_t n = (size_t)q->n;
+    ProjQueries dq;
+    dq.n = q->n;
+    const float* dUR = nullptr;
+    if ((rc = stage_in(m, SL_VALID, q->valid, n, mem_space, &dq.valid)) || (rc = stage_in(m, SL_U, q->u, n, mem_space, &dq.u)) ||
+        (rc = stage_in(m, SL_V, q->v, n, mem_space, &dq.v)) || (rc = stage_in(m, SL_QR, q->radius, n, mem_space, &dq.radius)) ||
+        (rc = stage_in(m, SL_QMIN, (const int*)q->min_level, n, mem_space, &dq.minLevel)) ||
+        (rc = stage_in(m, SL_QMAX, (const int*)q->max_level, n, mem_space, &dq.maxLevel)) ||
+        (rc = stage_in(m, SL_QDESC, q->desc, n * 32, mem_space, &dq.desc)) ||
+        (rc = stage_in(m, SL_QX, q->angle, n, mem_space, &dq.angle)) ||
+        (rc = stage_in(m, SL_HASOBS, q->has_obs, n, mem_space, &dq.hasObs)) ||
+        (rc = stage_in(m, SL_INVZ, q->u_right, n, mem_space, &dq.uRight)) ||
+        (rc = stage_in(m, SL_QY, q->right_gate, n, mem_space, &dq.rightGate)) ||
+        (rc = stage_in(m, SL_URIGHT, train_u_right, (size_t)dt.n, mem_space, &dUR)))
+        return rc;
+    ProjPolicy pol = {p->claim_rule, p->max_dist, p->ratio_test, p->nn_ratio, p->check_orientation};
+    return run_projected(m, dt, dUR, dq, pol, claimed, claimed_obs, query_best, nmatches, mem_space);
+}
+
+int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm_frame* last, const uint8_t* mp_desc,
+                              const uint8_t* valid, const float* u, const float* v, const float* invz,
+                              const uint8_t* has_obs, const float* cur_u_right, const float* scale_factors, int nlevels,
+                              float bf, float th, int direction, int check_orientation, int32_t* cur_claimed,
+                              uint8_t* cur_claimed_obs, int32_t* query_best, int* nmatches, int mem_space) {
     int rc = use_device(m);
     if (rc) return rc;
     if (!valid || !u || !v || !invz || !has_obs || !cur_u_right || !scale_factors || nlevels < 1 || !cur_claimed ||
@@ -938,66 +1097,43 @@ int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm
     DevFrame dc, dl;
     if ((rc = make_frame(m, cur, SL_F2_KPS, SL_F2_DESC, mem_space, &dc))) return rc;
     if ((rc = make_frame(m, last, SL_F1_KPS, SL_F1_DESC, mem_space, &dl))) return rc;
-    *nmatches = 0;
-    if (dl.n == 0 || dc.n == 0) return ORBX_OK;
-    int *cs, *ci;
-    if ((rc = build_grid(m, dc, &cs, &ci))) return rc;
-    const int nl = dl.n, nc = dc.n;
-    ProjArgs a;
-    if ((rc = stage_in(m, SL_VALID, valid, (size_t)nl, mem_space, &a.valid)) ||
-        (rc = stage_in(m, SL_U, u, (size_t)nl, mem_space, &a.u)) || (rc = stage_in(m, SL_V, v, (size_t)nl, mem_space, &a.v)) ||
-        (rc = stage_in(m, SL_INVZ, invz, (size_t)nl, mem_space, &a.invz)) ||
-        (rc = stage_in(m, SL_HASOBS, has_obs, (size_t)nl, mem_space, &a.hasObs)) ||
-        (rc = stage_in(m, SL_URIGHT, cur_u_right, (size_t)nc, mem_space, &a.curURight)))
+    const int nl = dl.n;
+    const u8 *dValid, *dHasObs, *dMpDesc;
+    const float *dU, *dV, *dInvz, *dUR;
+    if ((rc = stage_in(m, SL_VALID, valid, (size_t)nl, mem_space, &dValid)) ||
+        (rc = stage_in(m, SL_U, u, (size_t)nl, mem_space, &dU)) || (rc = stage_in(m, SL_V, v, (size_t)nl, mem_space, &dV)) ||
+        (rc = stage_in(m, SL_INVZ, invz, (size_t)nl, mem_space, &dInvz)) ||
+        (rc = stage_in(m, SL_HASOBS, has_obs, (size_t)nl, mem_space, &dHasObs)) ||
+        (rc = stage_in(m, SL_QDESC, mp_desc, (size_t)nl * 32, mem_space, &dMpDesc)) ||
+        (rc = stage_in(m, SL_URIGHT, cur_u_right, (size_t)dc.n, mem_space, &dUR)))
         return rc;
-    {
-        // scale factors are a small host table in both memory spaces' callers; accept either
-        void* p;
-        if ((rc = pool_get(m, SL_SF, (size_t)nlevels * sizeof(float), &p))) return rc;
-        ORBX_HIP_CHECK(hipMemcpyAsync(p, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyDefault, m->stream));
-        a.scaleFactors = (const float*)p;
-    }
-    a.bf = bf;
-    a.th = th;
-    a.direction = direction;
-    void *cnt, *offs, *qb, *qn, *scal;
-    if ((rc = pool_get(m, SL_COUNTS, (size_t)nl * 4, &cnt)) || (rc = pool_get(m, SL_OFFS, (size_t)(nl + 1) * 4, &offs)) ||
-        (rc = pool_get(m, SL_STATE_C, (size_t)nl * 4, &qb)) || (rc = pool_get(m, SL_STATE_D, (size_t)nl * 4, &qn)) ||
-        (rc = pool_get(m, SL_SCALAR, 64, &scal)))
+    void *sf, *qv, *qr, *qmin, *qmax, *qa, *qur;
+    const size_t n1 = (size_t)std::max(nl, 1);
+    if ((rc = pool_get(m, SL_SF, (size_t)nlevels * sizeof(float), &sf)) || (rc = pool_get(m, SL_KNN_Q, n1, &qv)) ||
+        (rc = pool_get(m, SL_QR, n1 * 4, &qr)) || (rc = pool_get(m, SL_QMIN, n1 * 4, &qmin)) ||
+        (rc = pool_get(m, SL_QMAX, n1 * 4, &qmax)) || (rc = pool_get(m, SL_QX, n1 * 4, &qa)) ||
+        (rc = pool_get(m, SL_QY, n1 * 4, &qur)))
         return rc;
-    hipLaunchKernelGGL(k_proj_candidates, dim3((nl + 3) / 4), dim3(256), 0, m->stream, dc, dl, (const int*)cs, (const int*)ci,
-                       a, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, nl);
-    int total = 0;
-    ORBX_HIP_CHECK(hipMemcpyAsync(&total, (int*)offs + nl, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
-    void *cIdx, *cDist;
-    if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
-        (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
-        return rc;
-    hipLaunchKernelGGL(k_proj_candidates, dim3((nl + 3) / 4), dim3(256), 0, m->stream, dc, dl, (const int*)cs, (const int*)ci,
-                       a, 2, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr);
-    int* dClaim;
-    u8* dClaimObs;
-    if (mem_space == ORBX_MEM_DEVICE) {
-        dClaim = (int*)cur_claimed;
-        dClaimObs = cur_claimed_obs;
-    } else {
-        void *p1, *p2;
-        if ((rc = pool_get(m, SL_STATE_A, (size_t)nc * 4, &p1)) || (rc = pool_get(m, SL_STATE_B, (size_t)nc, &p2))) return rc;
-        dClaim = (int*)p1;
-        dClaimObs = (u8*)p2;
-        ORBX_HIP_CHECK(hipMemcpyAsync(dClaim, cur_claimed, (size_t)nc * 4, hipMemcpyHostToDevice, m->stream));
-        ORBX_HIP_CHECK(hipMemcpyAsync(dClaimObs, cur_claimed_obs, (size_t)nc, hipMemcpyHostToDevice, m->stream));
-    }
-    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), 0, m->stream, dc, dl, a, (const int*)offs, (const int*)cIdx,
-                       (const int*)cDist, check_orientation, dClaim, dClaimObs, (int*)qb, (int*)qn, (int*)scal);
-    ORBX_HIP_CHECK(hipGetLastError());
-    if ((rc = copy_back(m, (int*)cur_claimed, (const int*)dClaim, (size_t)nc, mem_space))) return rc;
-    if ((rc = copy_back(m, cur_claimed_obs, (const u8*)dClaimObs, (size_t)nc, mem_space))) return rc;
-    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, scal, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
-    return ORBX_OK;
+    ORBX_HIP_CHECK(hipMemcpyAsync(sf, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyDefault, m->stream));
+    if (nl > 0)
+        hipLaunchKernelGGL(k_m4_queries, dim3((nl + 255) / 256), dim3(256), 0, m->stream, dc, dl, dValid, dU, dV, dInvz,
+                           (const float*)sf, bf, th, direction, (u8*)qv, (float*)qr, (int*)qmin, (int*)qmax, (float*)qa,
+                           (float*)qur);
+    ProjQueries dq;
+    dq.n = nl;
+    dq.valid = (const u8*)qv;
+    dq.u = dU;
+    dq.v = dV;
+    dq.radius = (const float*)qr;
+    dq.minLevel = (const int*)qmin;
+    dq.maxLevel = (const int*)qmax;
+    dq.desc = mp_desc ? dMpDesc : dl.desc;
+    dq.angle = (const float*)qa;
+    dq.hasObs = dHasObs;
+    dq.uRight = (const float*)qur;
+    dq.rightGate = (const float*)qr;  // er > radius rejects (reference :1619)
+    ProjPolicy pol = {0, TH_HIGH, 0, 0.f, check_orientation};
+    return run_projected(m, dc, dUR, dq, pol, cur_claimed, cur_claimed_obs, query_best, nmatches, mem_space);
 }
 
 int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int train_index_base,

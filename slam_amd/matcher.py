@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import KP_DTYPE, MEM_HOST, MFrame, check
+from ._lib import KP_DTYPE, MEM_HOST, MFrame, ProjPolicy, ProjQueries, check
 
 
 class FrameView:
@@ -105,13 +105,67 @@ class ORBmatcher:
             int(windowSize), self.mfNNratio, int(self.mbCheckOrientation), C.byref(n), MEM_HOST))
         return n.value, m12[:F1.N].copy(), pm
 
-    # ---- reference src/ORBmatcher.cc:1533-1678
+    # ---- projected searches
+    def _claims(self, n, claimed, claimed_obs):
+        cl = np.full(max(n, 1), -1, np.int32) if claimed is None else np.array(claimed, np.int32)
+        co = np.zeros(max(n, 1), np.uint8) if claimed_obs is None else np.array(claimed_obs, np.uint8)
+        return cl, co
+
+    def search_projected(self, train, valid, u, v, radius, min_level, max_level, desc, policy,
+                         angle=None, has_obs=None, u_right=None, right_gate=None, claimed=None,
+                         claimed_obs=None):
+        """Generic form (orbm_search_projected).  policy = (claim_rule, max_dist, ratio_test,
+        nn_ratio, check_orientation).  Returns (nmatches, claimed, claimed_obs, query_best)."""
+        n = len(u)
+        keep = []
+
+        def arr(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return a.ctypes.data
+
+        q = ProjQueries(n, arr(valid, np.uint8), arr(u, np.float32), arr(v, np.float32),
+                        arr(radius, np.float32), arr(min_level, np.int32), arr(max_level, np.int32),
+                        arr(np.asarray(desc).reshape(-1, 32), np.uint8), arr(angle, np.float32),
+                        arr(has_obs, np.uint8), arr(u_right, np.float32), arr(right_gate, np.float32))
+        pol = ProjPolicy(int(policy[0]), int(policy[1]), int(policy[2]), float(policy[3]), int(policy[4]))
+        cl, co = self._claims(train.N, claimed, claimed_obs)
+        qb = np.full(max(n, 1), -1, np.int32)
+        nm = C.c_int(0)
+        check(self._lib.orbm_search_projected(self._m, C.byref(train.c), train.u_right.ctypes.data,
+                                              C.byref(q), C.byref(pol), cl.ctypes.data,
+                                              co.ctypes.data, qb.ctypes.data, C.byref(nm), MEM_HOST))
+        return nm.value, cl[:train.N].copy(), co[:train.N].copy(), qb[:n].copy()
+
+    # reference src/ORBmatcher.cc:62-155 (and RadiusByViewingCos :158-164)
+    def SearchByProjectionMapPoints(self, F, valid, proj_x, proj_y, proj_xr, level, view_cos, desc,
+                                    has_obs, th=3.0, claimed=None, claimed_obs=None):
+        """SearchByProjection(Frame&, const vector<MapPoint*>&, th): per local map point the
+        fields set by Frame::isInFrustum (mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos);
+        valid = mbTrackInView && !isBad()."""
+        level = np.ascontiguousarray(level, np.int32)
+        # `viewCos > 0.998` compares the float against a double literal (reference :160)
+        r = np.where(np.asarray(view_cos, np.float32).astype(np.float64) > 0.998, np.float32(2.5), np.float32(4.0))
+        r = r.astype(np.float32)
+        if float(th) != 1.0:
+            r = (r * np.float32(th)).astype(np.float32)
+        radius = (r * F.scale_factors[level]).astype(np.float32)
+        pol = (0, self.TH_HIGH, 1, self.mfNNratio, 0)
+        return self.search_projected(F, valid, proj_x, proj_y, radius, level - 1, level, desc, pol,
+                                     has_obs=has_obs, u_right=proj_xr, right_gate=radius,
+                                     claimed=claimed, claimed_obs=claimed_obs)
+
+    # reference src/ORBmatcher.cc:1533-1678 (perfect/src/ORBmatcher.cc:1726 adds the point lists)
     def SearchByProjection(self, CurrentFrame, LastFrame, th, valid, u, v, invz, has_obs, bf,
-                           direction=0, claimed=None, claimed_obs=None):
+                           direction=0, claimed=None, claimed_obs=None, mp_desc=None,
+                           return_query_best=False):
         """Frame-to-frame projection search.  The caller supplies, per last-frame keypoint,
         the projection into the current frame (u, v, invz), whether it carries a usable map
-        point (valid) and whether that point has observations (has_obs); `direction` is 0
-        (neither), 1 (forward) or 2 (backward).  Returns (nmatches, claimed, claimed_obs):
+        point (valid), whether that point has observations (has_obs) and the map points'
+        descriptors (mp_desc; default: the last frame's keypoint descriptors); `direction` is
+        0 (neither), 1 (forward) or 2 (backward).  Returns (nmatches, claimed, claimed_obs):
         claimed[i2] is the last-frame index assigned to current keypoint i2, or -1."""
         nl, nc = LastFrame.N, CurrentFrame.N
         valid = np.ascontiguousarray(valid, np.uint8)
@@ -120,17 +174,53 @@ class ORBmatcher:
         invz = np.ascontiguousarray(invz, np.float32)
         has_obs = np.ascontiguousarray(has_obs, np.uint8)
         assert len(valid) == len(u) == len(v) == len(invz) == len(has_obs) == nl
-        cl = np.full(max(nc, 1), -1, np.int32) if claimed is None else np.array(claimed, np.int32)
-        co = np.zeros(max(nc, 1), np.uint8) if claimed_obs is None else np.array(claimed_obs, np.uint8)
+        md = None if mp_desc is None else np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        cl, co = self._claims(nc, claimed, claimed_obs)
+        qb = np.full(max(nl, 1), -1, np.int32)
         n = C.c_int(0)
         sf = CurrentFrame.scale_factors
         check(self._lib.orbm_search_by_projection(
-            self._m, C.byref(CurrentFrame.c), C.byref(LastFrame.c), valid.ctypes.data,
+            self._m, C.byref(CurrentFrame.c), C.byref(LastFrame.c),
+            md.ctypes.data if md is not None else None, valid.ctypes.data,
             u.ctypes.data, v.ctypes.data, invz.ctypes.data, has_obs.ctypes.data,
             CurrentFrame.u_right.ctypes.data, sf.ctypes.data, len(sf), float(bf), float(th),
             int(direction), int(self.mbCheckOrientation), cl.ctypes.data, co.ctypes.data,
-            C.byref(n), MEM_HOST))
+            qb.ctypes.data, C.byref(n), MEM_HOST))
+        if return_query_best:
+            return n.value, cl[:nc].copy(), co[:nc].copy(), qb[:nl].copy()
         return n.value, cl[:nc].copy(), co[:nc].copy()
+
+    # reference src/ORBmatcher.cc:1694-1836
+    def SearchByProjectionKeyFrame(self, CurrentFrame, valid, u, v, level, desc, kf_angle, th, ORBdist,
+                                   claimed=None):
+        """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) from the point
+        where each keyframe map point is projected (u, v) and its level predicted; valid
+        folds pMP != NULL, !isBad(), !sAlreadyFound.count(pMP) and the distance check."""
+        level = np.ascontiguousarray(level, np.int32)
+        u = np.ascontiguousarray(u, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        b = CurrentFrame.bounds
+        ok = np.asarray(valid, bool) & ~((u < np.float32(b[0])) | (u > np.float32(b[2]))) & \
+            ~((v < np.float32(b[1])) | (v > np.float32(b[3])))
+        radius = (np.float32(th) * CurrentFrame.scale_factors[level]).astype(np.float32)
+        pol = (1, int(ORBdist), 0, 0.0, int(self.mbCheckOrientation))
+        return self.search_projected(CurrentFrame, ok.astype(np.uint8), u, v, radius, level - 1, level + 1,
+                                     desc, pol, angle=kf_angle, claimed=claimed)
+
+    # reference src/ORBmatcher.cc:370-485
+    def SearchByProjectionSim3(self, KF, valid, u, v, level, desc, th, matched=None):
+        """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) from the point where each
+        candidate map point is projected with the Sim3 (u, v) and its level predicted; valid
+        folds the bad/already-found/depth/distance/viewing-angle checks."""
+        level = np.ascontiguousarray(level, np.int32)
+        u = np.ascontiguousarray(u, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        b = KF.bounds
+        inimg = (u >= np.float32(b[0])) & (u < np.float32(b[2])) & (v >= np.float32(b[1])) & (v < np.float32(b[3]))
+        radius = (np.float32(int(th)) * KF.scale_factors[level]).astype(np.float32)
+        pol = (1, self.TH_LOW, 0, 0.0, 0)
+        return self.search_projected(KF, (np.asarray(valid, bool) & inimg).astype(np.uint8), u, v, radius,
+                                     level - 1, level, desc, pol, claimed=matched)
 
     # ---- brute force
     def knn2(self, q, t, index_base=0):

@@ -237,3 +237,113 @@ def test_knn2_large_roundtrip_property(matcher):
     assert np.array_equal(bi, perm.astype(np.int32))
     assert (bd == 0).all() and (sd > 60).all()
     assert matcher.ratio_test(bd, sd, 50).all()
+
+
+# ---------------------------------------------------------------- the other projection searches
+def map_point_inputs(frames, seed, n=1500):
+    """Synthetic local map points seen in view b: projections near b's keypoints or random."""
+    (ka, da), (kb, db) = frames["a"], frames["b"]
+    rng = np.random.RandomState(seed)
+    src = rng.randint(0, len(kb), n)
+    px = (kb["x"][src] + rng.normal(0, 2.0, n)).astype(np.float32)
+    py = (kb["y"][src] + rng.normal(0, 2.0, n)).astype(np.float32)
+    far = rng.uniform(size=n) < 0.2
+    px[far] = rng.uniform(-30, 680, far.sum()).astype(np.float32)
+    py[far] = rng.uniform(-30, 510, far.sum()).astype(np.float32)
+    level = np.clip(kb["octave"][src] + rng.randint(-1, 2, n), 0, 7).astype(np.int32)
+    desc = synth.perturb_descriptors(db[src], seed, max_flips=40)
+    rnd = rng.uniform(size=n) < 0.15
+    desc[rnd] = synth.synth_descriptors(int(rnd.sum()), seed + 1)
+    valid = (rng.uniform(size=n) < 0.85).astype(np.uint8)
+    has_obs = (rng.uniform(size=n) < 0.8).astype(np.uint8)
+    view_cos = rng.choice(np.array([0.9, 0.998, 0.99800003, 0.9995], np.float32), n)
+    pxr = (px - rng.uniform(0, 30, n)).astype(np.float32)
+    ur = np.full(len(kb), -1.0, np.float32)
+    pick = rng.uniform(size=len(kb)) < 0.5
+    ur[pick] = (kb["x"][pick] - rng.uniform(0, 30, pick.sum())).astype(np.float32)
+    return dict(valid=valid, px=px, py=py, pxr=pxr, level=level, view_cos=view_cos, desc=desc,
+                has_obs=has_obs, ur=ur, angle=rng.uniform(0, 360, n).astype(np.float32))
+
+
+@pytest.mark.parametrize("th,ratio", [(1.0, 0.8), (3.0, 0.8), (5.0, 0.6)])
+def test_search_by_projection_map_points(oracle, frames, th, ratio):
+    from slam_amd.matcher import FrameView, ORBmatcher
+    kb, db = frames["b"]
+    q = map_point_inputs(frames, 3)
+    rng = np.random.RandomState(8)
+    claimed = np.full(len(kb), -1, np.int32)
+    cobs = np.zeros(len(kb), np.uint8)
+    pick = rng.uniform(size=len(kb)) < 0.2     # points tracked from the previous frame
+    claimed[pick] = 0
+    cobs[pick] = (rng.uniform(size=pick.sum()) < 0.7).astype(np.uint8)
+    F = FrameView(kb, db, BOUNDS, frames["sf"], u_right=q["ur"])
+    oF = oracle.FrameData(kb, db, BOUNDS, frames["sf"])
+    m = ORBmatcher(ratio, True)
+    n, cl, co, qb = m.SearchByProjectionMapPoints(F, q["valid"], q["px"], q["py"], q["pxr"], q["level"],
+                                                  q["view_cos"], q["desc"], q["has_obs"], th, claimed, cobs)
+    rn, rcl, rco = oracle.search_by_projection_mappoints(oF, q["ur"], q["valid"], q["px"], q["py"], q["pxr"],
+                                                         q["level"], q["view_cos"], q["desc"], q["has_obs"], th,
+                                                         ratio, claimed, cobs)
+    assert n == rn and n > 100
+    assert np.array_equal(cl, rcl) and np.array_equal(co, rco)
+    m.close()
+
+
+@pytest.mark.parametrize("th,orbdist,ori", [(10.0, 100, True), (3.0, 64, True), (10.0, 100, False)])
+def test_search_by_projection_keyframe(oracle, frames, th, orbdist, ori):
+    from slam_amd.matcher import FrameView, ORBmatcher
+    kb, db = frames["b"]
+    q = map_point_inputs(frames, 4)
+    rng = np.random.RandomState(9)
+    claimed = np.full(len(kb), -1, np.int32)
+    claimed[rng.uniform(size=len(kb)) < 0.25] = 7     # found earlier by the BoW search
+    F = FrameView(kb, db, BOUNDS, frames["sf"])
+    oF = oracle.FrameData(kb, db, BOUNDS, frames["sf"])
+    m = ORBmatcher(0.9, ori)
+    n, cl, _, _ = m.SearchByProjectionKeyFrame(F, q["valid"], q["px"], q["py"], q["level"], q["desc"], q["angle"],
+                                               th, orbdist, claimed)
+    rn, rcl = oracle.search_by_projection_keyframe(oF, q["valid"], q["px"], q["py"], q["level"], q["desc"],
+                                                   q["angle"], th, orbdist, ori, claimed)
+    assert n == rn and n > 50
+    assert np.array_equal(cl, rcl)
+    m.close()
+
+
+@pytest.mark.parametrize("th", [10, 3])
+def test_search_by_projection_sim3(oracle, frames, th):
+    from slam_amd.matcher import FrameView, ORBmatcher
+    kb, db = frames["b"]
+    q = map_point_inputs(frames, 5)
+    q["px"][:5] = 640.0     # KeyFrame::IsInImage is exclusive at the upper bound
+    rng = np.random.RandomState(10)
+    matched = np.full(len(kb), -1, np.int32)
+    matched[rng.uniform(size=len(kb)) < 0.3] = 3
+    K = FrameView(kb, db, BOUNDS, frames["sf"])
+    oK = oracle.FrameData(kb, db, BOUNDS, frames["sf"])
+    m = ORBmatcher(0.75, True)
+    n, cl, _, _ = m.SearchByProjectionSim3(K, q["valid"], q["px"], q["py"], q["level"], q["desc"], th, matched)
+    rn, rcl = oracle.search_by_projection_sim3(oK, q["valid"], q["px"], q["py"], q["level"], q["desc"], th, matched)
+    assert n == rn and n > 50
+    assert np.array_equal(cl, rcl)
+    m.close()
+
+
+def test_search_by_projection_frames_with_map_point_descriptors(oracle, frames):
+    """The query descriptor is the map point's (pMP->GetDescriptor()), not the last frame's
+    keypoint descriptor; query_best gives the matched pairs before the orientation cull."""
+    from slam_amd.matcher import FrameView, ORBmatcher
+    (ka, da), (kb, db) = frames["a"], frames["b"]
+    valid, u, v, invz, has_obs, ur = projection_inputs(frames, 77)
+    mpd = synth.perturb_descriptors(da, 5, max_flips=25)
+    cur = FrameView(kb, db, BOUNDS, frames["sf"], u_right=ur)
+    last = FrameView(ka, da, BOUNDS, frames["sf"])
+    ocur = oracle.FrameData(kb, db, BOUNDS, frames["sf"])
+    olast = oracle.FrameData(ka, da, BOUNDS, frames["sf"])
+    m = ORBmatcher(0.9, True)
+    n, cl, co, qb = m.SearchByProjection(cur, last, 15.0, valid, u, v, invz, has_obs, 40.0, 0, mp_desc=mpd,
+                                         return_query_best=True)
+    rn, rcl, rco, rqb = oracle.search_by_projection_frames(ocur, olast, valid, u, v, invz, has_obs, ur, 40.0, 15.0,
+                                                           0, True, mp_desc=mpd, return_query_best=True)
+    assert n == rn and np.array_equal(cl, rcl) and np.array_equal(co, rco)
+    assert np.array_equal(qb, rqb) and (qb >= 0).sum() >= n
+    m.close()
