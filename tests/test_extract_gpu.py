@@ -190,3 +190,48 @@ def test_device_fast_atan2_equals_oracle(oracle, extractor_vga):
     ref = np.array([oracle.fast_atan2(float(a), float(b)) for a, b in zip(y[:20000], x[:20000])], np.float32)
     assert np.array_equal(got[:20000].view(np.uint32), ref.view(np.uint32))
     assert (got >= 0).all() and (got <= 360).all()
+
+
+def test_4k_10k_features(oracle):
+    """BASELINE config 5 shape: 3840x2160, 10 000 features (largest quadtree tables)."""
+    from slam_amd.extractor import ORBextractor
+    ex = ORBextractor(10000, 1.2, 8, 20, 7, max_width=3840, max_height=2160, max_batch=1)
+    try:
+        img = synth.synth_image(3840, 2160, 4000)
+        kps, desc = ex(img, None)
+        rk, rd = oracle.extract(oracle.params(nfeatures=10000), img, cap=10400)
+        assert len(rk) >= 10000
+        assert_same_features(kps, desc, rk, rd, "4K")
+    finally:
+        ex.close()
+
+
+def test_large_batch_properties(extractor_vga):
+    """At a batch size the oracle is too slow for: size-independent properties.  Identical
+    frames give identical outputs wherever they sit in the batch, and every output obeys
+    the extractor's invariants."""
+    import torch
+    from slam_amd._lib import KP_DTYPE
+    ex = extractor_vga
+    base = synth.synth_batch_torch(8, 640, 480, 5000, device="cuda")
+    B = 96
+    frames = base.repeat(B // 8, 1, 1).contiguous()
+    cap = ex.max_keypoints()
+    d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ex.extract_batch_device(frames, d_kps, d_desc, d_n, cap)
+    ex.synchronize()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(KP_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+    for f in range(8, B):
+        assert n[f] == n[f % 8]
+        assert np.array_equal(kps[f, :n[f]], kps[f % 8, :n[f]])
+        assert np.array_equal(desc[f, :n[f]], desc[f % 8, :n[f]])
+    for f in range(8):
+        k = kps[f, :n[f]]
+        assert 1000 <= n[f] <= cap
+        assert (np.diff(k["octave"]) >= 0).all() and (k["class_id"] == -1).all()
+        assert (k["angle"] >= 0).all() and (k["angle"] <= 360).all()
