@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -774,6 +775,145 @@ int oracle_extract_batch(const oracle_params* p, const uint8_t* imgs, int nframe
     for (int f = 0; f < nframes; f++)
         if (rc[f]) return rc[f];
     return 0;
+}
+
+// reference src/Frame.cc:603-774, Frame::ComputeStereoMatches.  mvImagePyramid of the two
+// extractors is rebuilt here from the two images.  Returns the number of stereo points.
+int oracle_compute_stereo_matches(const oracle_params* p, const uint8_t* img_left, const uint8_t* img_right, int w, int h,
+                                  size_t stride, const oracle_keypoint* keys, const uint8_t* desc, int N,
+                                  const oracle_keypoint* keys_right, const uint8_t* desc_right, int Nr, float mb,
+                                  float mbf, float* mvuRight, float* mvDepth) {
+    Tables t = make_tables(*p);
+    std::vector<Image> pyrL, pyrR;
+    build_pyramid(t, img_left, w, h, stride, p->nlevels, pyrL);
+    build_pyramid(t, img_right, w, h, stride, p->nlevels, pyrR);
+    for (int i = 0; i < N; i++) {
+        mvuRight[i] = -1.0f;
+        mvDepth[i] = -1.0f;
+    }
+    const int TH_HIGH = 100, TH_LOW = 50;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = pyrL[0].h;
+    std::vector<std::vector<size_t>> vRowIndices(nRows, std::vector<size_t>());
+    for (int iR = 0; iR < Nr; iR++) {
+        const oracle_keypoint& kp = keys_right[iR];
+        const float& kpY = kp.y;
+        const float r = 2.0f * t.scale[keys_right[iR].octave];
+        const int maxr = ceil(kpY + r);
+        const int minr = floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);
+    }
+    const float minZ = mb;
+    const float minD = 0;
+    const float maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    auto popdist = [](const uint8_t* a, const uint8_t* b) {
+        int d = 0;
+        for (int i = 0; i < 32; i++) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+        return d;
+    };
+    for (int iL = 0; iL < N; iL++) {
+        const oracle_keypoint& kpL = keys[iL];
+        const int& levelL = kpL.octave;
+        const float& vL = kpL.y;
+        const float& uL = kpL.x;
+        const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD;
+        const float maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        size_t bestIdxR = 0;
+        const uint8_t* dL = desc + (size_t)iL * 32;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            const oracle_keypoint& kpR = keys_right[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float& uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = popdist(dL, desc_right + iR * 32);
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdxR = iR;
+                }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = keys_right[bestIdxR].x;
+            const float scaleFactor = t.inv_scale[kpL.octave];
+            const float scaleduL = round(kpL.x * scaleFactor);
+            const float scaledvL = round(kpL.y * scaleFactor);
+            const float scaleduR0 = round(uR0 * scaleFactor);
+            const int wnd = 5;
+            const Image& IMG_L = pyrL[kpL.octave];
+            const Image& IMG_R = pyrR[kpL.octave];
+            float IL[11][11];
+            {
+                const int r0 = (int)(scaledvL - wnd), c0 = (int)(scaleduL - wnd);
+                for (int y = 0; y < 11; y++)
+                    for (int x = 0; x < 11; x++) IL[y][x] = (float)IMG_L.row(r0 + y)[c0 + x];
+                const float c = IL[wnd][wnd];
+                for (int y = 0; y < 11; y++)
+                    for (int x = 0; x < 11; x++) IL[y][x] = IL[y][x] - c * 1.0f;
+            }
+            int bestDistSAD = INT_MAX;
+            int bestincR = 0;
+            const int L = 5;
+            std::vector<float> vDists;
+            vDists.resize(2 * L + 1);
+            const float iniu = scaleduR0 + L - wnd;
+            const float endu = scaleduR0 + L + wnd + 1;
+            if (iniu < 0 || endu >= IMG_R.w) continue;
+            for (int incR = -L; incR <= +L; incR++) {
+                float IR[11][11];
+                const int r0 = (int)(scaledvL - wnd), c0 = (int)(scaleduR0 + incR - wnd);
+                for (int y = 0; y < 11; y++)
+                    for (int x = 0; x < 11; x++) IR[y][x] = (float)IMG_R.row(r0 + y)[c0 + x];
+                const float c = IR[wnd][wnd];
+                float dist = 0;
+                for (int y = 0; y < 11; y++)
+                    for (int x = 0; x < 11; x++) dist += fabsf(IL[y][x] - (IR[y][x] - c * 1.0f));
+                if (dist < bestDistSAD) {
+                    bestDistSAD = dist;
+                    bestincR = incR;
+                }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1];
+            const float dist2 = vDists[L + bestincR];
+            const float dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = t.scale[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {
+                    disparity = 0.01;
+                    bestuR = uL - 0.01;
+                }
+                mvDepth[iL] = mbf / disparity;
+                mvuRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDistSAD, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return 0;  // the reference indexes an empty vector here
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    int kept = (int)vDistIdx.size();
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist)
+            break;
+        else {
+            mvuRight[vDistIdx[i].second] = -1;
+            mvDepth[vDistIdx[i].second] = -1;
+            kept--;
+        }
+    }
+    return kept;
 }
 
 }  // extern "C"

@@ -81,6 +81,12 @@ int oracle_extract_batch(const oracle_params* p, const uint8_t* imgs, int nframe
                          size_t row_stride, size_t img_stride, oracle_keypoint* kps, uint8_t* desc,
                          int cap_per_frame, int* n_out, int threads);
 
+/* Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) on a rectified pair. */
+int oracle_compute_stereo_matches(const oracle_params* p, const uint8_t* img_left, const uint8_t* img_right, int w, int h,
+                                  size_t stride, const oracle_keypoint* keys, const uint8_t* desc, int n,
+                                  const oracle_keypoint* keys_right, const uint8_t* desc_right, int n_right, float mb,
+                                  float mbf, float* u_right, float* depth);
+
 /* ---- grid + matcher: reference src/Frame.cc, src/ORBmatcher.cc ---- */
 #define ORACLE_GRID_COLS 64
 #define ORACLE_GRID_ROWS 48

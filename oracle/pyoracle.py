@@ -183,6 +183,22 @@ def extract_batch(p, imgs, cap=None, threads=1):
     return kps, desc, n
 
 
+def compute_stereo_matches(p, img_left, img_right, kl, dl, kr, dr, mb, mbf):
+    il = np.ascontiguousarray(img_left, np.uint8)
+    ir = np.ascontiguousarray(img_right, np.uint8)
+    assert il.shape == ir.shape
+    kl = np.ascontiguousarray(kl, KP_DTYPE)
+    kr = np.ascontiguousarray(kr, KP_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8)
+    dr = np.ascontiguousarray(dr, np.uint8)
+    ur = np.zeros(max(len(kl), 1), np.float32)
+    dp = np.zeros(max(len(kl), 1), np.float32)
+    n = lib().oracle_compute_stereo_matches(C.byref(p), _p(il), _p(ir), il.shape[1], il.shape[0],
+                                            C.c_size_t(il.strides[0]), _p(kl), _p(dl), len(kl), _p(kr), _p(dr),
+                                            len(kr), C.c_float(mb), C.c_float(mbf), _p(ur), _p(dp))
+    return n, ur[:len(kl)].copy(), dp[:len(kl)].copy()
+
+
 # ---------------------------------------------------------------- matching
 class FrameData:
     """Keeps the numpy buffers alive behind an oracle_frame struct."""

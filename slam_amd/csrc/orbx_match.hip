@@ -620,51 +620,76 @@ __global__ void k_init_queries(DevFrame f1, const float* prevMatched, float wind
 }
 
 // ------------------------------------------------------------------ brute-force kNN-2
-#define KNN_QPT 2      // queries per thread
-#define KNN_TILE 256   // train descriptors per LDS tile
+__device__ __forceinline__ u32 umed3(u32 a, u32 b, u32 c) {
+    u32 r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
-// Each thread keeps KNN_QPT query descriptors in registers; train descriptors
-// stream through LDS in tiles and are read as wave-wide broadcasts.
+#define KNN_QPT 4          // queries per thread
+#define KNN_IDX_BITS 22    // train rows per launch chunk: (distance << 22) | row fits 32 bits
+
+// Each thread keeps KNN_QPT query descriptors in registers.  Every thread of the grid walks
+// the same train rows in the same order, so a train descriptor is a wave-uniform value: it is
+// fetched with scalar loads and used as the scalar operand of XOR (no LDS, no barriers).  The
+// two smallest (distance, row) keys are kept with  second = med3(best, second, key);
+// best = min(best, key): unique keys make "first row wins ties" and "second counts duplicates
+// of the minimum" fall out of the ordering.
 __global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt,
-                                               int indexBase, int* bestIdx, int* bestD, int* secondD) {
-    __shared__ uint4 tile[KNN_TILE * 2];
+                                               int indexBase, int* bestIdx, int* bestD, int* secondD, int mergeWithOutput) {
     const int tid = threadIdx.x;
     const int q0 = (blockIdx.x * 256 + tid) * KNN_QPT;
     uint4 qa[KNN_QPT][2];
-    int best[KNN_QPT], second[KNN_QPT], idx[KNN_QPT];
+    u32 best[KNN_QPT], second[KNN_QPT];
 #pragma unroll
     for (int k = 0; k < KNN_QPT; k++) {
         const int qi = min(q0 + k, nq - 1);
         qa[k][0] = q[(i64)qi * 2];
         qa[k][1] = q[(i64)qi * 2 + 1];
-        best[k] = 256;
-        second[k] = 256;
-        idx[k] = -1;
+        best[k] = 0xFFFFFFFFu;
+        second[k] = 0xFFFFFFFFu;
     }
-    for (int base = 0; base < nt; base += KNN_TILE) {
-        const int cnt = min(KNN_TILE, nt - base);
-        __syncthreads();
-        for (int i = tid; i < cnt * 2; i += 256) tile[i] = t[(i64)base * 2 + i];
-        __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < cnt; j++) {
-            const uint4 b0 = tile[2 * j], b1 = tile[2 * j + 1];
+    auto visit = [&](const uint4 b0, const uint4 b1, int j) {
 #pragma unroll
-            for (int k = 0; k < KNN_QPT; k++) {
-                const int d = hamming256(qa[k][0], qa[k][1], b0, b1);
-                const bool lt = d < best[k];
-                second[k] = lt ? best[k] : min(second[k], d);
-                idx[k] = lt ? base + j : idx[k];
-                best[k] = min(best[k], d);
-            }
+        for (int k = 0; k < KNN_QPT; k++) {
+            const u32 d = (u32)hamming256(qa[k][0], qa[k][1], b0, b1);
+            const u32 key = (d << KNN_IDX_BITS) | (u32)j;
+            second[k] = umed3(best[k], second[k], key);
+            best[k] = min(best[k], key);
         }
+    };
+    int j = 0;
+    // four train rows per trip: their scalar loads are issued together, ahead of the math
+    for (; j + 4 <= nt; j += 4) {
+        uint4 b[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) b[r] = t[(i64)j * 2 + r];
+#pragma unroll
+        for (int r = 0; r < 4; r++) visit(b[2 * r], b[2 * r + 1], j + r);
     }
+    for (; j < nt; j++) visit(t[(i64)j * 2], t[(i64)j * 2 + 1], j);
 #pragma unroll
     for (int k = 0; k < KNN_QPT; k++) {
         if (q0 + k < nq) {
-            bestIdx[q0 + k] = idx[k] < 0 ? -1 : idx[k] + indexBase;
-            bestD[q0 + k] = best[k];
-            secondD[q0 + k] = second[k];
+            // a distance of 256 never replaces the initial 256 (strict '<' from 256)
+            int bd = best[k] == 0xFFFFFFFFu ? 256 : (int)(best[k] >> KNN_IDX_BITS);
+            int bi = (bd >= 256) ? -1 : (int)(best[k] & ((1u << KNN_IDX_BITS) - 1)) + indexBase;
+            int sd = second[k] == 0xFFFFFFFFu ? 256 : (int)(second[k] >> KNN_IDX_BITS);
+            bd = min(bd, 256);
+            sd = min(sd, 256);
+            if (mergeWithOutput) {
+                // earlier chunk of the same train set is already in the output arrays
+                const int pb = bestD[q0 + k], ps = secondD[q0 + k], pi = bestIdx[q0 + k];
+                const int s2 = min(max(pb, bd), min(ps, sd));
+                if (!(bd < pb)) {
+                    bd = pb;
+                    bi = pi;
+                }
+                sd = s2;
+            }
+            bestIdx[q0 + k] = bi;
+            bestD[q0 + k] = bd;
+            secondD[q0 + k] = sd;
         }
     }
 }
@@ -1159,8 +1184,14 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
     if ((rc = stage_out(m, SL_KNN_D, (int*)best_d, (size_t)nq, mem_space, &dd))) return rc;
     if ((rc = stage_out(m, SL_KNN_S, (int*)second_d, (size_t)nq, mem_space, &ds))) return rc;
     const int blocks = (nq + 256 * KNN_QPT - 1) / (256 * KNN_QPT);
-    hipLaunchKernelGGL(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt, nt,
-                       train_index_base, di, dd, ds);
+    const int chunkRows = 1 << KNN_IDX_BITS;
+    int c0 = 0;
+    do {
+        const int rows = std::min(chunkRows, nt - c0);
+        hipLaunchKernelGGL(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq,
+                           (const uint4*)(dt + (size_t)c0 * 32), rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0);
+        c0 += rows;
+    } while (c0 < nt);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)best_idx, (const int*)di, (size_t)nq, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)best_d, (const int*)dd, (size_t)nq, mem_space))) return rc;
