@@ -262,6 +262,30 @@ int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm
                               int check_orientation, int32_t* cur_claimed, uint8_t* cur_claimed_obs,
                               int32_t* query_best, int* nmatches, int mem_space);
 
+/* Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for a rectified pair.
+ * left/right: mvKeys / mDescriptors and mvKeysRight / mDescriptorsRight (the grid bounds of
+ * orbm_frame are not read).  pyr_left / pyr_right: mvImagePyramid of the two extractors
+ * (reference include/ORBextractor.h:73) as DEVICE images, e.g. from orbx_get_level; the
+ * extractor work that produced them must have completed (orbx_extract returns after it has;
+ * after a device-space orbx_extract_batch call orbx_synchronize first).  scale_factors /
+ * inv_scale_factors: mvScaleFactors / mvInvScaleFactors, nlevels entries each.  mb, mbf:
+ * baseline in metres and baseline times fx.  u_right / depth (left->n floats): mvuRight and
+ * mvDepth, -1 where no stereo point was found.  *n_stereo (may be NULL; host memory): number of
+ * stereo points kept after the median cut (:763-774); asking for it makes the call synchronous.
+ * Where the reference would index outside its row table or cut an image window that leaves the
+ * pyramid level (cv::Mat range assertion), the keypoint gets no match instead. */
+#define ORBM_MAX_LEVELS 16
+typedef struct orbm_pyramid {
+    int32_t nlevels;
+    const uint8_t* level[ORBM_MAX_LEVELS];
+    int32_t width[ORBM_MAX_LEVELS], height[ORBM_MAX_LEVELS];
+    size_t pitch[ORBM_MAX_LEVELS];
+} orbm_pyramid;
+int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const orbm_frame* right,
+                                const orbm_pyramid* pyr_left, const orbm_pyramid* pyr_right,
+                                const float* scale_factors, const float* inv_scale_factors, float mb,
+                                float mbf, float* u_right, float* depth, int* n_stereo, int mem_space);
+
 /* Brute-force 2-nearest-neighbour search over 256-bit descriptors with the
  * serial-scan semantics of the reference's descriptor loops
  * (src/ORBmatcher.cc:255-282): best = smallest distance, lowest train index on

@@ -231,9 +231,44 @@ public:
         return n;
     }
 
+    // Frame::ComputeStereoMatches (reference src/Frame.cc:603-774).  left/right are the two
+    // extractors right after they produced keys/keysRight (their device pyramids are read in
+    // place); mvuRight and mvDepth come back with N entries, -1 where there is no stereo point.
+    int ComputeStereoMatches(ORBextractor& left, ORBextractor& right, const orbx::KeyPoint* keys,
+                             const unsigned char* descriptors, int N, const orbx::KeyPoint* keysRight,
+                             const unsigned char* descriptorsRight, int Nr, float mb, float mbf, std::vector<float>& mvuRight,
+                             std::vector<float>& mvDepth) {
+        mvuRight.assign(N, -1.0f);
+        mvDepth.assign(N, -1.0f);
+        if (N == 0) return 0;
+        orbm_pyramid pl = pyramid(left), pr = pyramid(right);
+        orbm_frame fl = {reinterpret_cast<const orbx_keypoint*>(keys), descriptors, N, 0, 0, 1, 1};
+        orbm_frame fr = {reinterpret_cast<const orbx_keypoint*>(keysRight), descriptorsRight, Nr, 0, 0, 1, 1};
+        int n = 0;
+        orbx::check(orbm_compute_stereo_matches(m_, &fl, &fr, &pl, &pr, orbx_scale_factors(left.handle()),
+                                                orbx_inv_scale_factors(left.handle()), mb, mbf, mvuRight.data(),
+                                                mvDepth.data(), &n, ORBX_MEM_HOST),
+                    "orbm_compute_stereo_matches");
+        return n;
+    }
+
     orbm_context* context() { return m_; }
 
 protected:
+    static orbm_pyramid pyramid(ORBextractor& e) {
+        orbm_pyramid p;
+        std::memset(&p, 0, sizeof(p));
+        p.nlevels = e.GetLevels();
+        for (int l = 0; l < p.nlevels; l++) {
+            int w = 0, h = 0;
+            size_t st = 0;
+            p.level[l] = e.PyramidLevelDevice(l, &w, &h, &st);
+            p.width[l] = w;
+            p.height[l] = h;
+            p.pitch[l] = st;
+        }
+        return p;
+    }
     float mfNNratio;
     bool mbCheckOrientation;
     orbm_context* m_ = nullptr;

@@ -798,6 +798,7 @@ int oracle_compute_stereo_matches(const oracle_params* p, const uint8_t* img_lef
     for (int iR = 0; iR < Nr; iR++) {
         const oracle_keypoint& kp = keys_right[iR];
         const float& kpY = kp.y;
+        if (kp.octave < 0 || kp.octave >= p->nlevels) continue;  // outside mvScaleFactors: undefined in the reference
         const float r = 2.0f * t.scale[keys_right[iR].octave];
         const int maxr = ceil(kpY + r);
         const int minr = floor(kpY - r);
@@ -818,6 +819,8 @@ int oracle_compute_stereo_matches(const oracle_params* p, const uint8_t* img_lef
         const int& levelL = kpL.octave;
         const float& vL = kpL.y;
         const float& uL = kpL.x;
+        if (levelL < 0 || levelL >= p->nlevels) continue;
+        if (!(vL >= 0.0f) || !(vL < (float)nRows)) continue;  // outside the row table: undefined in the reference
         const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
         if (vCandidates.empty()) continue;
         const float minU = uL - maxD;
@@ -848,6 +851,15 @@ int oracle_compute_stereo_matches(const oracle_params* p, const uint8_t* img_lef
             const int wnd = 5;
             const Image& IMG_L = pyrL[kpL.octave];
             const Image& IMG_R = pyrR[kpL.octave];
+            {
+                // windows leaving the level image: cv::Mat range assertion in the reference
+                const int r0 = (int)(scaledvL - wnd), cl0 = (int)(scaleduL - wnd), cr0 = (int)(scaleduR0 - wnd);
+                const float iniu0 = scaleduR0 + 5 - wnd, endu0 = scaleduR0 + 5 + wnd + 1;
+                if (!(iniu0 < 0 || endu0 >= IMG_R.w) &&
+                    (r0 < 0 || r0 + 10 >= IMG_L.h || cl0 < 0 || cl0 + 10 >= IMG_L.w || cr0 - 5 < 0 || cr0 + 15 >= IMG_R.w))
+                    continue;
+                if (iniu0 < 0 || endu0 >= IMG_R.w) continue;
+            }
             float IL[11][11];
             {
                 const int r0 = (int)(scaledvL - wnd), c0 = (int)(scaleduL - wnd);

@@ -46,6 +46,14 @@ class MFrame(C.Structure):
                 ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
 
 
+MAX_LEVELS = 16
+
+
+class Pyramid(C.Structure):
+    _fields_ = [("nlevels", C.c_int32), ("level", C.c_void_p * MAX_LEVELS), ("width", C.c_int32 * MAX_LEVELS),
+                ("height", C.c_int32 * MAX_LEVELS), ("pitch", C.c_size_t * MAX_LEVELS)]
+
+
 # Every exported symbol of include/orbx.h: (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -92,6 +100,8 @@ SIGNATURES = {
     "orbm_search_by_projection": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp, _vp,
                                        C.POINTER(_i), _i]),
+    "orbm_compute_stereo_matches": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), C.POINTER(Pyramid),
+                                         C.POINTER(Pyramid), _vp, _vp, _f, _f, _vp, _vp, _vp, _i]),
     "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
     "orbm_knn2_merge": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
 }

@@ -629,6 +629,238 @@ __device__ __forceinline__ u32 umed3(u32 a, u32 b, u32 c) {
 #define KNN_QPT 4          // queries per thread
 #define KNN_IDX_BITS 22    // train rows per launch chunk: (distance << 22) | row fits 32 bits
 
+// ------------------------------------------------------------------ stereo
+// Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for a rectified
+// pair.  The reference's per-row candidate lists are replaced by a direct scan:
+// a right keypoint is a candidate of image row v when floor(y - r) <= v <=
+// ceil(y + r), r = 2*scale[octave] (:618-630); scanning right keypoints in index
+// order visits them in the order the row list holds them.
+const int MAX_LEVELS = ORBM_MAX_LEVELS;
+
+struct DevPyramid {
+    const u8* ptr[MAX_LEVELS];
+    int pitch[MAX_LEVELS], w[MAX_LEVELS], h[MAX_LEVELS];
+};
+
+struct StereoParams {
+    float scale[MAX_LEVELS], invScale[MAX_LEVELS];
+    int nlevels, nRows;
+    float mbf, maxD;
+};
+
+__global__ void k_stereo_rows(DevFrame right, StereoParams sp, int4* rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= right.n) return;
+    const orbx_keypoint kp = right.kps[i];
+    int4 o = make_int4(1, 0, kp.octave, __float_as_int(kp.x));  // empty band for an octave outside the pyramid
+    if (kp.octave >= 0 && kp.octave < sp.nlevels) {
+        const float r = 2.0f * sp.scale[kp.octave];
+        o.y = (int)ceilf(kp.y + r);
+        o.x = (int)floorf(kp.y - r);
+    }
+    rows[i] = o;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per left keypoint: descriptor argmin over the row band, then the 11x11 SAD
+// search over 11 column shifts on the keypoint's pyramid level and the parabola fit.
+// sad[iL] receives the best SAD (the key of the later median cut) or -1.
+__global__ __launch_bounds__(256) void k_stereo_match(DevFrame left, DevFrame right, const int4* __restrict__ rows,
+                                                      DevPyramid pl, DevPyramid pr, StereoParams sp, float* uRight,
+                                                      float* depth, int* sad) {
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (iL >= left.n) return;
+    const orbx_keypoint kpL = left.kps[iL];
+    const float uL = kpL.x, vL = kpL.y;
+    const int levelL = kpL.octave;
+    float outU = -1.0f, outD = -1.0f;
+    int outS = -1;
+    do {
+        if (levelL < 0 || levelL >= sp.nlevels) break;
+        if (!(vL >= 0.0f) || !(vL < (float)sp.nRows)) break;
+        const int row = (int)vL;
+        const float minD = 0;
+        const float minU = uL - sp.maxD;
+        const float maxU = uL - minD;
+        if (maxU < 0) break;
+        const uint4* dl = (const uint4*)(left.desc + (size_t)iL * 32);
+        const uint4 a0 = dl[0], a1 = dl[1];
+        u64 best = ~0ull;
+        for (int base = 0; base < right.n; base += 64) {
+            const int i = base + lane;
+            if (i < right.n) {
+                const int4 rw = rows[i];
+                const float uR = __int_as_float(rw.w);
+                if (rw.x <= row && row <= rw.y && rw.z >= levelL - 1 && rw.z <= levelL + 1 && uR >= minU && uR <= maxU) {
+                    const uint4* dr = (const uint4*)(right.desc + (size_t)i * 32);
+                    const int d = hamming256(a0, a1, dr[0], dr[1]);
+                    if (d < TH_HIGH) {  // bestDist starts at TH_HIGH, strict < (:650, :672)
+                        const u64 key = ((u64)d << 32) | (u32)i;
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        }
+        best = wave_min_u64(best);
+        if (best == ~0ull) break;
+        const int bestDist = (int)(best >> 32);
+        const int bestIdxR = (int)(u32)best;
+        if (!(bestDist < (TH_HIGH + TH_LOW) / 2)) break;  // thOrbDist, :608
+
+        // :684-690
+        const float uR0 = right.kps[bestIdxR].x;
+        const float scaleFactor = sp.invScale[levelL];
+        const float scaleduL = roundf(uL * scaleFactor);
+        const float scaledvL = roundf(vL * scaleFactor);
+        const float scaleduR0 = roundf(uR0 * scaleFactor);
+        const int w = 5, L = 5;
+        const float iniu = scaleduR0 + L - w;
+        const float endu = scaleduR0 + L + w + 1;
+        if (iniu < 0 || endu >= pr.w[levelL]) break;  // :706-709
+        // Every pixel the windows touch must exist (the reference's cv::Mat ranges throw otherwise).
+        const int r0 = (int)(scaledvL - w), cl0 = (int)(scaleduL - w), cr0 = (int)(scaleduR0 - w);
+        if (r0 < 0 || r0 + 2 * w >= pl.h[levelL] || r0 + 2 * w >= pr.h[levelL] || cl0 < 0 || cl0 + 2 * w >= pl.w[levelL] ||
+            cr0 - L < 0 || cr0 + L + 2 * w >= pr.w[levelL])
+            break;
+
+        const int p0 = lane, p1 = lane + 64;
+        const bool has1 = p1 < 121;
+        const int y0 = p0 / 11, x0 = p0 - y0 * 11;
+        const int y1 = has1 ? p1 / 11 : 0, x1 = has1 ? p1 - y1 * 11 : 0;
+        const int pitchL = pl.pitch[levelL], pitchR = pr.pitch[levelL];
+        const u8* Lp = pl.ptr[levelL] + (size_t)r0 * pitchL + cl0;
+        const int cL = Lp[w * pitchL + w];
+        const int il0 = (int)Lp[y0 * pitchL + x0] - cL;
+        const int il1 = (int)Lp[y1 * pitchL + x1] - cL;
+        int bestDistSAD = 0x7fffffff, bestincR = 0;
+        int d1 = 0, d2 = 0, d3 = 0, prev = 0;
+        bool wantNext = false;
+        for (int incR = -L; incR <= L; incR++) {
+            const u8* Rp = pr.ptr[levelL] + (size_t)r0 * pitchR + (cr0 + incR);
+            const int cR = Rp[w * pitchR + w];
+            int s = abs(il0 - ((int)Rp[y0 * pitchR + x0] - cR));
+            if (has1) s += abs(il1 - ((int)Rp[y1 * pitchR + x1] - cR));
+            s = wave_sum_i32(s);
+            if (wantNext) {
+                d3 = s;
+                wantNext = false;
+            }
+            if (s < bestDistSAD) {  // :719-723
+                bestDistSAD = s;
+                bestincR = incR;
+                d1 = prev;
+                d2 = s;
+                wantNext = true;
+            }
+            prev = s;
+        }
+        if (bestincR == -L || bestincR == L) break;  // :728-729
+        // :732-737
+        const float dist1 = (float)d1, dist2 = (float)d2, dist3 = (float)d3;
+        const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+        if (deltaR < -1 || deltaR > 1) break;
+        // :743-758
+        float bestuR = sp.scale[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+        float disparity = (uL - bestuR);
+        if (disparity >= minD && disparity < sp.maxD) {
+            if (disparity <= 0) {
+                disparity = 0.01;
+                bestuR = uL - 0.01;
+            }
+            outD = sp.mbf / disparity;
+            outU = bestuR;
+            outS = bestDistSAD;
+        }
+    } while (0);
+    if (lane == 0) {
+        uRight[iL] = outU;
+        depth[iL] = outD;
+        sad[iL] = outS;
+    }
+}
+
+// :763-774: median of the accepted SAD distances (element size/2 of the sorted list),
+// then every match with distance >= 1.5*1.4*median is dropped.  SAD <= 121*510, so the
+// median comes from two LDS histogram passes (high bits, then low bits).
+__global__ __launch_bounds__(1024) void k_stereo_median(int n, const int* __restrict__ sad, float* uRight, float* depth,
+                                                        int* kept) {
+    __shared__ int hist[1024];
+    __shared__ int sh[4];
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    if (tid < 4) sh[tid] = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const int d = sad[i];
+        if (d >= 0) {
+            atomicAdd(&hist[min(d >> 6, 1023)], 1);
+            cnt++;
+        }
+    }
+    atomicAdd(&sh[0], cnt);
+    __syncthreads();
+    const int total = sh[0];
+    if (total == 0) {
+        if (tid == 0 && kept) *kept = 0;
+        return;
+    }
+    const int k = total / 2;
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 1024; b++) {
+            if (acc + hist[b] > k) break;
+            acc += hist[b];
+        }
+        sh[1] = b;
+        sh[2] = k - acc;
+    }
+    __syncthreads();
+    const int hb = sh[1], k2 = sh[2];
+    __syncthreads();
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int d = sad[i];
+        if (d >= 0 && min(d >> 6, 1023) == hb) atomicAdd(&hist[hb == 1023 ? min(d - (1023 << 6), 1023) : (d & 63)], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 1024; b++) {
+            if (acc + hist[b] > k2) break;
+            acc += hist[b];
+        }
+        sh[1] = (hb << 6) + b;
+        sh[3] = 0;
+    }
+    __syncthreads();
+    const float median = sh[1];
+    const float thDist = 1.5f * 1.4f * median;
+    int mine = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const int d = sad[i];
+        if (d < 0) continue;
+        if (d < thDist)
+            mine++;
+        else {
+            uRight[i] = -1;
+            depth[i] = -1;
+        }
+    }
+    if (kept) {
+        atomicAdd(&sh[3], mine);
+        __syncthreads();
+        if (tid == 0) *kept = sh[3];
+    }
+}
+
 // Each thread keeps KNN_QPT query descriptors in registers.  Every thread of the grid walks
 // the same train rows in the same order, so a train descriptor is a wave-uniform value: it is
 // fetched with scalar loads and used as the scalar operand of XOR (no LDS, no barriers).  The
@@ -741,7 +973,8 @@ enum {
     SL_F1_KPS = 0, SL_F1_DESC, SL_F2_KPS, SL_F2_DESC, SL_CELL_START, SL_CELL_ITEMS, SL_CELL_OF, SL_QX, SL_QY,
     SL_QR, SL_QMIN, SL_QMAX, SL_QDESC, SL_COUNTS, SL_OFFS, SL_CAND_IDX, SL_CAND_DIST, SL_STATE_A, SL_STATE_B,
     SL_STATE_C, SL_STATE_D, SL_PREV, SL_SCALAR, SL_VALID, SL_U, SL_V, SL_INVZ, SL_HASOBS, SL_URIGHT, SL_SF,
-    SL_KNN_Q, SL_KNN_T, SL_KNN_I, SL_KNN_D, SL_KNN_S, SL_KNN_I2, SL_KNN_D2, SL_KNN_S2
+    SL_KNN_Q, SL_KNN_T, SL_KNN_I, SL_KNN_D, SL_KNN_S, SL_KNN_I2, SL_KNN_D2, SL_KNN_S2, SL_ST_ROWS, SL_ST_SAD,
+    SL_ST_U, SL_ST_D
 };
 
 // Device view of a caller array: the pointer itself for device memory, else a staged copy.
@@ -1159,6 +1392,83 @@ int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm
     dq.rightGate = (const float*)qr;  // er > radius rejects (reference :1619)
     ProjPolicy pol = {0, TH_HIGH, 0, 0.f, check_orientation};
     return run_projected(m, dc, dUR, dq, pol, cur_claimed, cur_claimed_obs, query_best, nmatches, mem_space);
+}
+
+static int fill_pyramid(const orbm_pyramid* p, DevPyramid* d, const char* which) {
+    if (!p || p->nlevels < 1 || p->nlevels > MAX_LEVELS) {
+        orbx_set_error("%s pyramid: nlevels must be in [1, %d]", which, MAX_LEVELS);
+        return ORBX_ERR_INVALID;
+    }
+    memset(d, 0, sizeof(*d));
+    for (int l = 0; l < p->nlevels; l++) {
+        if (!p->level[l] || p->width[l] <= 0 || p->height[l] <= 0 || p->pitch[l] < (size_t)p->width[l] ||
+            p->pitch[l] > 0x7fffffff) {
+            orbx_set_error("%s pyramid: level %d is not a valid image", which, l);
+            return ORBX_ERR_INVALID;
+        }
+        d->ptr[l] = p->level[l];
+        d->pitch[l] = (int)p->pitch[l];
+        d->w[l] = p->width[l];
+        d->h[l] = p->height[l];
+    }
+    return ORBX_OK;
+}
+
+int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const orbm_frame* right,
+                                const orbm_pyramid* pyr_left, const orbm_pyramid* pyr_right, const float* scale_factors,
+                                const float* inv_scale_factors, float mb, float mbf, float* u_right, float* depth,
+                                int* n_stereo, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (!scale_factors || !inv_scale_factors || !u_right || !depth || !pyr_left || !pyr_right) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    DevPyramid pl, pr;
+    if ((rc = fill_pyramid(pyr_left, &pl, "left"))) return rc;
+    if ((rc = fill_pyramid(pyr_right, &pr, "right"))) return rc;
+    if (pyr_left->nlevels != pyr_right->nlevels) {
+        orbx_set_error("left and right pyramids differ in depth");
+        return ORBX_ERR_INVALID;
+    }
+    DevFrame dl, dr;
+    if ((rc = make_frame(m, left, SL_F1_KPS, SL_F1_DESC, mem_space, &dl))) return rc;
+    if ((rc = make_frame(m, right, SL_F2_KPS, SL_F2_DESC, mem_space, &dr))) return rc;
+    if (n_stereo) *n_stereo = 0;
+    if (dl.n == 0) return ORBX_OK;
+    StereoParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.nlevels = pyr_left->nlevels;
+    for (int l = 0; l < sp.nlevels; l++) {
+        sp.scale[l] = scale_factors[l];
+        sp.invScale[l] = inv_scale_factors[l];
+    }
+    sp.nRows = pl.h[0];  // reference src/Frame.cc:610
+    sp.mbf = mbf;
+    // reference src/Frame.cc:633-636
+    const float minZ = mb;
+    sp.maxD = mbf / minZ;
+    void *dRows, *dSad, *dKept;
+    if ((rc = pool_get(m, SL_ST_ROWS, (size_t)std::max(dr.n, 1) * sizeof(int4), &dRows))) return rc;
+    if ((rc = pool_get(m, SL_ST_SAD, (size_t)dl.n * sizeof(int), &dSad))) return rc;
+    if ((rc = pool_get(m, SL_SCALAR, 64, &dKept))) return rc;
+    float *dU, *dD;
+    if ((rc = stage_out(m, SL_ST_U, u_right, (size_t)dl.n, mem_space, &dU))) return rc;
+    if ((rc = stage_out(m, SL_ST_D, depth, (size_t)dl.n, mem_space, &dD))) return rc;
+    if (dr.n) {
+        hipLaunchKernelGGL(k_stereo_rows, dim3((dr.n + 255) / 256), dim3(256), 0, m->stream, dr, sp, (int4*)dRows);
+        ORBX_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_stereo_match, dim3((dl.n + 3) / 4), dim3(256), 0, m->stream, dl, dr, (const int4*)dRows, pl, pr, sp,
+                       dU, dD, (int*)dSad);
+    ORBX_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_stereo_median, dim3(1), dim3(1024), 0, m->stream, dl.n, (const int*)dSad, dU, dD, (int*)dKept);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, u_right, (const float*)dU, (size_t)dl.n, mem_space))) return rc;
+    if ((rc = copy_back(m, depth, (const float*)dD, (size_t)dl.n, mem_space))) return rc;
+    if (n_stereo) ORBX_HIP_CHECK(hipMemcpyAsync(n_stereo, dKept, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if (mem_space == ORBX_MEM_HOST || n_stereo) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
 }
 
 int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int train_index_base,

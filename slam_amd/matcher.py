@@ -222,6 +222,40 @@ class ORBmatcher:
         return self.search_projected(KF, (np.asarray(valid, bool) & inimg).astype(np.uint8), u, v, radius,
                                      level - 1, level, desc, pol, claimed=matched)
 
+    # ---- stereo
+    @staticmethod
+    def pyramid_of(extractor, frame=0):
+        """mvImagePyramid of `frame` of the extractor's last call as device images."""
+        p = _lib.Pyramid()
+        p.nlevels = extractor.GetLevels()
+        for l in range(p.nlevels):
+            ptr, w, h, st = extractor.level_info(frame, l)
+            p.level[l], p.width[l], p.height[l], p.pitch[l] = ptr, w, h, st
+        return p
+
+    def ComputeStereoMatches(self, ext_left, ext_right, keys, desc, keys_right, desc_right, mb, mbf,
+                             frame_left=0, frame_right=0):
+        """Frame::ComputeStereoMatches (reference src/Frame.cc:603-774): returns (mvuRight, mvDepth,
+        number of stereo points).  ext_left / ext_right are the two extractors whose last call
+        produced the keypoints (their pyramids are read in place on the device)."""
+        kl = np.ascontiguousarray(keys, KP_DTYPE)
+        kr = np.ascontiguousarray(keys_right, KP_DTYPE)
+        dl = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        dr = np.ascontiguousarray(desc_right, np.uint8).reshape(-1, 32)
+        fl = MFrame(kl.ctypes.data, dl.ctypes.data, len(kl), 0, 0, 1, 1)
+        fr = MFrame(kr.ctypes.data, dr.ctypes.data, len(kr), 0, 0, 1, 1)
+        pl = self.pyramid_of(ext_left, frame_left)
+        pr = self.pyramid_of(ext_right, frame_right)
+        sf = np.ascontiguousarray(ext_left.GetScaleFactors(), np.float32)
+        isf = np.ascontiguousarray(ext_left.GetInverseScaleFactors(), np.float32)
+        ur = np.full(max(len(kl), 1), -1, np.float32)
+        dp = np.full(max(len(kl), 1), -1, np.float32)
+        n = C.c_int(0)
+        check(self._lib.orbm_compute_stereo_matches(self._m, C.byref(fl), C.byref(fr), C.byref(pl), C.byref(pr),
+                                                    sf.ctypes.data, isf.ctypes.data, mb, mbf, ur.ctypes.data,
+                                                    dp.ctypes.data, C.addressof(n), MEM_HOST))
+        return ur[:len(kl)], dp[:len(kl)], n.value
+
     # ---- brute force
     def knn2(self, q, t, index_base=0):
         q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)

@@ -67,6 +67,23 @@ def synth_batch(n, w, h, seed0):
     return out
 
 
+def synth_stereo_pair(w, h, seed, disparity_top, disparity_bottom, noise=0):
+    """A rectified pair cut from one scene: rows above h/2 are displaced by disparity_top
+    pixels between the views, the rest by disparity_bottom; the right view gets uniform
+    noise in [-noise, noise].  Returns (left, right), (h, w) uint8 each."""
+    margin = 64
+    assert 0 <= disparity_top <= margin and 0 <= disparity_bottom <= margin
+    scene = synth_image(w + 2 * margin, h, seed)
+    left = np.ascontiguousarray(scene[:, margin:margin + w])
+    right = np.empty_like(left)
+    right[:h // 2] = scene[:h // 2, margin + disparity_top:margin + disparity_top + w]
+    right[h // 2:] = scene[h // 2:, margin + disparity_bottom:margin + disparity_bottom + w]
+    if noise:
+        r = (hash_u64(seed, w * h, 70) % np.uint64(2 * noise + 1)).astype(np.int32).reshape(h, w) - noise
+        right = np.clip(right.astype(np.int32) + r, 0, 255).astype(np.uint8)
+    return left, np.ascontiguousarray(right)
+
+
 def synth_descriptors(n, seed):
     """n random 256-bit descriptors as (n, 32) uint8."""
     v = hash_u64(seed, n * 4, 7)

@@ -2,7 +2,9 @@
 // extractor (reference src/Frame.cc:320-326).  Reads a raw 8-bit image, writes the
 // keypoints and descriptors as raw bytes; the Python test compares them with the
 // result obtained through ctypes.
-//   shim_check <raw image> <width> <height> <out file>
+//   shim_check <raw image> <width> <height> <out file> [<raw right image>]
+// With a right image it also runs the stereo matcher the way Frame::ComputeStereoMatches would
+// (reference src/Frame.cc:603) and appends mvuRight and mvDepth to the output.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -10,7 +12,7 @@
 #include "../../include/orbx_shim.hpp"
 
 int main(int argc, char** argv) {
-    if (argc != 5) {
+    if (argc != 5 && argc != 6) {
         std::fprintf(stderr, "usage: shim_check img.raw w h out.bin\n");
         return 2;
     }
@@ -32,6 +34,24 @@ int main(int argc, char** argv) {
         std::fwrite(&n, 4, 1, o);
         std::fwrite(keys.data(), sizeof(orbx::KeyPoint), keys.size(), o);
         std::fwrite(desc.data(), 1, desc.size(), o);
+        if (argc == 6) {
+            std::vector<unsigned char> imgR((size_t)w * h);
+            FILE* fr = std::fopen(argv[5], "rb");
+            if (!fr || std::fread(imgR.data(), 1, imgR.size(), fr) != imgR.size()) return 3;
+            std::fclose(fr);
+            ORB_SLAM2::ORBextractor extractorRight(1000, 1.2f, 8, 20, 7, w, h);
+            std::vector<orbx::KeyPoint> keysRight;
+            std::vector<unsigned char> descRight;
+            orbx::Image imR = {imgR.data(), w, h, (size_t)w};
+            extractorRight(imR, none, keysRight, descRight);
+            ORB_SLAM2::ORBmatcher stereo;
+            std::vector<float> uRight, depth;
+            int ns = stereo.ComputeStereoMatches(extractor, extractorRight, keys.data(), desc.data(), n, keysRight.data(),
+                                                 descRight.data(), (int)keysRight.size(), 0.54f, 386.1448f, uRight, depth);
+            std::fwrite(&ns, 4, 1, o);
+            std::fwrite(uRight.data(), 4, uRight.size(), o);
+            std::fwrite(depth.data(), 4, depth.size(), o);
+        }
         std::fclose(o);
         std::printf("%d keypoints\n", n);
     } catch (const std::exception& e) {

@@ -85,6 +85,17 @@ def main():
                         knn_q=q, knn_t=t, knn_idx=bi, knn_d=bd, knn_s=sd)
     print("match", n_init, n_proj)
 
+    # stereo: KITTI-sized rectified pair, two disparity planes, noisy right view
+    p = O.params(nfeatures=2000)
+    left, right = synth.synth_stereo_pair(1241, 376, 61, 9, 33, 2)
+    kl, dl = O.extract(p, left, cap=2300)
+    kr, dr = O.extract(p, right, cap=2300)
+    n, ur, dp = O.compute_stereo_matches(p, left, right, kl, dl, kr, dr, 0.54, 386.1448)
+    np.savez_compressed(os.path.join(OUT, "stereo_kitti.npz"), w=1241, h=376, seed=61, dtop=9, dbot=33, noise=2,
+                        nfeatures=2000, left_sha1=sha(left), right_sha1=sha(right), mb=np.float32(0.54),
+                        mbf=np.float32(386.1448), n_left=len(kl), n_right=len(kr), n_stereo=n, u_right=ur, depth=dp)
+    print("stereo", len(kl), len(kr), n)
+
 
 if __name__ == "__main__":
     main()

@@ -19,7 +19,7 @@ def test_header_declares_the_expected_surface():
     names = declared_functions()
     for must in ("orbx_create", "orbx_destroy", "orbx_extract", "orbx_extract_batch", "orbx_get_level",
                  "orbx_scale_factors", "orbm_hamming256", "orbm_grid_build", "orbm_window_candidates",
-                 "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_knn2",
+                 "orbm_search_for_initialization", "orbm_search_by_projection", "orbm_compute_stereo_matches", "orbm_knn2",
                  "orbm_knn2_merge"):
         assert must in names
 

@@ -42,7 +42,7 @@ def same(k, d, z):
 
 def test_fixtures_exist():
     assert len(seeded_cases()) >= 5
-    for f in ("extract_small_stored.npz", "extract_low_contrast.npz", "match_pair.npz"):
+    for f in ("extract_small_stored.npz", "extract_low_contrast.npz", "match_pair.npz", "stereo_kitti.npz"):
         assert os.path.exists(os.path.join(G, f))
 
 
@@ -78,6 +78,52 @@ def test_oracle_reproduces_matching(oracle):
     assert np.array_equal(s, z["grid_start"]) and np.array_equal(it, z["grid_items"])
     bi, bd, sd = oracle.knn2(z["knn_q"], z["knn_t"])
     assert np.array_equal(bi, z["knn_idx"]) and np.array_equal(bd, z["knn_d"]) and np.array_equal(sd, z["knn_s"])
+
+
+def stereo_case():
+    z = np.load(os.path.join(G, "stereo_kitti.npz"))
+    left, right = synth.synth_stereo_pair(int(z["w"]), int(z["h"]), int(z["seed"]), int(z["dtop"]), int(z["dbot"]),
+                                          int(z["noise"]))
+    assert sha(left) == str(z["left_sha1"]) and sha(right) == str(z["right_sha1"])
+    return z, left, right
+
+
+def test_oracle_reproduces_stereo(oracle):
+    z, left, right = stereo_case()
+    p = oracle.params(nfeatures=int(z["nfeatures"]))
+    kl, dl = oracle.extract(p, left, cap=2300)
+    kr, dr = oracle.extract(p, right, cap=2300)
+    n, ur, dp = oracle.compute_stereo_matches(p, left, right, kl, dl, kr, dr, float(z["mb"]), float(z["mbf"]))
+    assert (len(kl), len(kr), n) == (int(z["n_left"]), int(z["n_right"]), int(z["n_stereo"]))
+    assert np.array_equal(ur.view(np.uint32), z["u_right"].view(np.uint32))
+    assert np.array_equal(dp.view(np.uint32), z["depth"].view(np.uint32))
+    # known answer: the two planted disparities dominate
+    d = (kl["x"] - ur)[ur >= 0]
+    top = kl["y"][ur >= 0] < int(z["h"]) // 2 - 20
+    bot = kl["y"][ur >= 0] > int(z["h"]) // 2 + 20
+    assert abs(np.median(d[top]) - int(z["dtop"])) < 0.5 and abs(np.median(d[bot]) - int(z["dbot"])) < 0.5
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_stereo():
+    from slam_amd.extractor import ORBextractor
+    from slam_amd.matcher import ORBmatcher
+    z, left, right = stereo_case()
+    nf = int(z["nfeatures"])
+    el = ORBextractor(nf, 1.2, 8, 20, 7, max_width=left.shape[1], max_height=left.shape[0])
+    er = ORBextractor(nf, 1.2, 8, 20, 7, max_width=left.shape[1], max_height=left.shape[0])
+    m = ORBmatcher(0.6, True)
+    try:
+        kl, dl = el(left, None)
+        kr, dr = er(right, None)
+        ur, dp, n = m.ComputeStereoMatches(el, er, kl, dl, kr, dr, float(z["mb"]), float(z["mbf"]))
+        assert (len(kl), len(kr), n) == (int(z["n_left"]), int(z["n_right"]), int(z["n_stereo"]))
+        assert np.array_equal(ur.view(np.uint32), z["u_right"].view(np.uint32))
+        assert np.array_equal(dp.view(np.uint32), z["depth"].view(np.uint32))
+    finally:
+        m.close()
+        el.close()
+        er.close()
 
 
 @pytest.mark.gpu

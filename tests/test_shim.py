@@ -47,3 +47,31 @@ def test_shim_matches_ctypes(tmp_path, extractor_vga):
     desc = np.frombuffer(blob[4 + 28 * n:], np.uint8).reshape(n, 32)
     k2, d2 = extractor_vga(img, None)
     assert n == len(k2) and np.array_equal(kps, k2) and np.array_equal(desc, d2)
+
+
+@pytest.mark.gpu
+def test_shim_stereo_matches_ctypes(tmp_path):
+    from slam_amd.extractor import ORBextractor
+    from slam_amd.matcher import ORBmatcher
+    exe = build(tmp_path)
+    left, right = synth.synth_stereo_pair(640, 480, 3, 14, 25, 2)
+    rawl, rawr = os.path.join(str(tmp_path), "l.raw"), os.path.join(str(tmp_path), "r.raw")
+    out = os.path.join(str(tmp_path), "o.bin")
+    left.tofile(rawl)
+    right.tofile(rawr)
+    subprocess.check_call([exe, rawl, "640", "480", out, rawr])
+    blob = open(out, "rb").read()
+    n = int(np.frombuffer(blob[:4], np.int32)[0])
+    tail = blob[4 + 60 * n:]
+    ns = int(np.frombuffer(tail[:4], np.int32)[0])
+    ur = np.frombuffer(tail[4:4 + 4 * n], np.float32)
+    dp = np.frombuffer(tail[4 + 4 * n:4 + 8 * n], np.float32)
+    el, er, m = ORBextractor(1000, 1.2, 8, 20, 7), ORBextractor(1000, 1.2, 8, 20, 7), ORBmatcher(0.6, True)
+    kl, dl = el(left, None)
+    kr, dr = er(right, None)
+    ur2, dp2, ns2 = m.ComputeStereoMatches(el, er, kl, dl, kr, dr, 0.54, 386.1448)
+    assert n == len(kl) and ns == ns2 and ns > 100
+    assert np.array_equal(ur.view(np.uint32), ur2.view(np.uint32)) and np.array_equal(dp.view(np.uint32), dp2.view(np.uint32))
+    m.close()
+    el.close()
+    er.close()
