@@ -76,6 +76,15 @@ __device__ __forceinline__ ImgRef level_image(const Geom& g, int l, ImgRef img0,
     return r;
 }
 
+// 24-bit multiplies run at the full vector rate; a 32-bit v_mul_lo_u32 takes several times
+// longer.  Every product below has operands under 2^24.
+__device__ __forceinline__ u32 mul24(u32 a, u32 b) { return __umul24(a, b); }
+__device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) {
+    u32 r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // ------------------------------------------------------------------ resize
 struct ResizeTap {
     u16 i0, i1;  // source indices (already clamped)
@@ -166,16 +175,17 @@ __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, 
     for (int y = y0; y < y1; y++) {
         const ResizeTap ty = yt[y];
         u32 ta[4], tb[4];
-        hsum((const u32*)(sbase + (i64)ty.i0 * src.pitch), ta);
-        hsum((const u32*)(sbase + (i64)ty.i1 * src.pitch), tb);
+        hsum((const u32*)(sbase + mul24(ty.i0, (u32)src.pitch)), ta);
+        hsum((const u32*)(sbase + mul24(ty.i1, (u32)src.pitch)), tb);
+        // weights are 0..2048 and t >> 4 < 2^15
         const u32 b0 = (u32)(int)ty.c0, b1 = (u32)(int)ty.c1;
         u32 out = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const u32 v = (((b0 * (ta[j] >> 4)) >> 16) + ((b1 * (tb[j] >> 4)) >> 16) + 2u) >> 2;
+            const u32 v = ((mul24(b0, ta[j] >> 4) >> 16) + (mul24(b1, tb[j] >> 4) >> 16) + 2u) >> 2;
             out |= (v & 0xFFu) << (8 * j);
         }
-        *(u32*)(dbase + (i64)y * dPitch) = out;
+        *(u32*)(dbase + mul24((u32)y, (u32)dPitch)) = out;
     }
 }
 
@@ -260,9 +270,11 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
     if (it < 0 || it >= G * L.blurBands) return;
     const int band = it / G, gx = it - band * G;
     const int w = L.w, h = L.h;
+    if (h < 4 || w < 4) return;  // such levels go through k_blur (the reflections below are single-step)
     const ImgRef im = level_image(g, l, img0, pyr);
     const u8* src = im.base + (i64)f * im.frameStride;
-    u8* dst = blur + (i64)f * g.blurFrameBytes + L.blurOff;
+    const u32 srcPitch = (u32)im.pitch, dstPitch = (u32)L.blurPitch;  // locals: nothing below re-reads the arguments
+    u8* dst = blur + (i64)f * g.blurFrameBytes + L.blurOff + 4 * gx;
     const int gl = max(gx - 1, 0), gr = min(gx + 1, G - 1);
     const bool lastGroup = gx == G - 1;
 
@@ -270,8 +282,9 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
     u32 selL = 0, selC = 0, selR = 0;
 #pragma unroll
     for (int p = 0; p < 12; p++) {
-        const int x = 4 * gx - 4 + p;
-        const int xr = reflect101(min(max(x, -3), w + 2), w);
+        const int x = min(max(4 * gx - 4 + p, -3), w + 2);
+        int xr = x < 0 ? -x : x;  // single-step reflect-101 (w >= 4 here)
+        xr = xr >= w ? 2 * (w - 1) - xr : xr;
         const int gs = xr >> 2, bs = xr & 3;
         u32 code;
         if (p < 8) {
@@ -291,14 +304,27 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
     const int y0 = band * BLUR_BH;
     const int yEnd = min(y0 + BLUR_BH, h);
 
-    u32 win[7][4];
-    auto load_row = [&](int y, u32* hs) {
-        const int r = reflect101(min(y, h + 2), h);
-        const u32* row = (const u32*)(src + (i64)r * im.pitch);
-        const u32 a = row[gl], c = row[gx], b = row[gr];
-        const u32 Lw = __builtin_amdgcn_perm(c, a, selL);
-        const u32 Cw = __builtin_amdgcn_perm(c, a, selC);
-        const u32 Rw = __builtin_amdgcn_perm(c, lastGroup ? a : b, selR);
+    // Rows are fetched one 7-row group ahead of their use: a wave keeps 7 rows (about 1.8 KB) in
+    // flight while it filters the previous group, which is what hides the HBM latency here.
+    struct Raw {
+        u32 a, c, b;
+    };
+    auto fetch = [&](int y) {
+        // one reflection covers y in [-3, h+2] (h >= 4 here)
+        y = min(y, h + 2);
+        int r = y < 0 ? -y : y;
+        r = r >= h ? 2 * (h - 1) - r : r;
+        const u32* row = (const u32*)(src + mul24((u32)r, srcPitch));
+        Raw o;
+        o.a = row[gl];
+        o.c = row[gx];
+        o.b = row[gr];
+        return o;
+    };
+    auto hrow = [&](const Raw& rw, u32* hs) {
+        const u32 Lw = __builtin_amdgcn_perm(rw.c, rw.a, selL);
+        const u32 Cw = __builtin_amdgcn_perm(rw.c, rw.a, selC);
+        const u32 Rw = __builtin_amdgcn_perm(rw.c, lastGroup ? rw.a : rw.b, selR);
         // output j uses bytes j+1..j+4 (taps k0..k3) and j+5..j+7 (taps k2,k1,k0)
         hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), W2,
                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), W1, 0u, false), false);
@@ -308,26 +334,48 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), W1, 0u, false), false);
         hs[3] = __builtin_amdgcn_udot4(Rw, W2, __builtin_amdgcn_udot4(Cw, W1, 0u, false), false);
     };
+    u32 win[7][4];
+    Raw cur[7];
+    {
+        Raw ini[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) load_row(y0 - 3 + i, win[i]);
+        for (int i = 0; i < 6; i++) ini[i] = fetch(y0 - 3 + i);
+#pragma unroll
+        for (int i = 0; i < 7; i++) cur[i] = fetch(y0 + 3 + i);
+#pragma unroll
+        for (int i = 0; i < 6; i++) hrow(ini[i], win[i]);
+    }
     for (int yb = y0; yb < yEnd; yb += 7) {
+        Raw nxt[7];
+        if (yb + 7 < yEnd) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) nxt[i] = fetch(yb + 10 + i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 7; i++) nxt[i] = cur[i];
+        }
 #pragma unroll
         for (int ph = 0; ph < 7; ph++) {
             const int y = yb + ph;
-            load_row(y + 3, win[(ph + 6) % 7]);
-            u32 out = 0;
+            hrow(cur[ph], win[(ph + 6) % 7]);
+            // row sums are < 2^16 and pair sums < 2^17: 24-bit multiplies.  The rounded sum is
+            // < 2^25; clamped to 0xFFFFFF its byte 2 is the saturated output pixel.
+            u32 sv[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const u32 s = (u32)k0 * (win[ph % 7][k] + win[(ph + 6) % 7][k]) +
-                              (u32)k1 * (win[(ph + 1) % 7][k] + win[(ph + 5) % 7][k]) +
-                              (u32)k2 * (win[(ph + 2) % 7][k] + win[(ph + 4) % 7][k]) +
-                              (u32)k3 * win[(ph + 3) % 7][k];
-                u32 v = (s + 32768u) >> 16;
-                v = v > 255u ? 255u : v;
-                out |= v << (8 * k);
+                u32 s = mad24((u32)k3, win[(ph + 3) % 7][k], 32768u);
+                s = mad24((u32)k2, win[(ph + 2) % 7][k] + win[(ph + 4) % 7][k], s);
+                s = mad24((u32)k1, win[(ph + 1) % 7][k] + win[(ph + 5) % 7][k], s);
+                s = mad24((u32)k0, win[ph % 7][k] + win[(ph + 6) % 7][k], s);
+                sv[k] = min(s, 0xFFFFFFu);
             }
-            if (y < yEnd) *(u32*)(dst + (i64)y * L.blurPitch + 4 * gx) = out;
+            const u32 lo = __builtin_amdgcn_perm(sv[1], sv[0], 0x0c0c0602u);  // bytes: sv0[2], sv1[2], 0, 0
+            const u32 hi = __builtin_amdgcn_perm(sv[3], sv[2], 0x06020c0cu);  // bytes: 0, 0, sv2[2], sv3[2]
+            const u32 out = lo | hi;
+            if (y < yEnd) *(u32*)(dst + mul24((u32)y, dstPitch)) = out;
         }
+#pragma unroll
+        for (int i = 0; i < 7; i++) cur[i] = nxt[i];
     }
 }
 
@@ -367,19 +415,58 @@ __device__ __forceinline__ int fast_strength(const int* d) {
 __device__ __forceinline__ u32 fastdiv(u32 i, u32 d, u32 magic) { return d == 1 ? i : __umulhi(i, magic); }
 __device__ __forceinline__ u32 div_magic(u32 d) { return d <= 1 ? 0u : (u32)(0x100000000ull / d) + 1u; }
 
+// Per-cell constants, computed on the host when the geometry is set up so that a wave
+// starts without divisions or level searches.
+//   w0 = level | roi width << 8 | roi height << 16      w1 = iniX | iniY << 16
+//   w2 = slot offset inside the frame's slot block        w3 = slot capacity | nk << 16
+//   w4 = gx0 | gy0 << 16 (detection-origin coordinates of the first interior pixel)
+//   w5 = magic(nW)   w6 = magic(nk)   w7 = nW
+// nW = 32-bit words per ROI row when rows are fetched from a 4-byte aligned address,
+// nk = words per row that hold interior pixels in that layout.
+struct FastCell {
+    u32 w[8];
+};
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 as_u16x2(u32 v) {
+    u16x2 r;
+    __builtin_memcpy(&r, &v, 4);
+    return r;
+}
+__device__ __forceinline__ u32 as_u32(u16x2 v) {
+    u32 r;
+    __builtin_memcpy(&r, &v, 4);
+    return r;
+}
+
+// Necessary condition for a FAST-9 corner on two pixels at once (16-bit halves): with
+// u/d/l/r the ring pixels 3 above, below, left and right of v, a 9-arc holds one pixel of
+// each opposite pair, so   max(min(u,d), min(l,r)) + th < v   (darker arc)   or
+// v + th < min(max(u,d), max(l,r))   (brighter arc)   must hold.  Returns the two sign bits.
+__device__ __forceinline__ u32 pair_test2(u32 v, u32 u, u32 d, u32 l, u32 r, u32 th2) {
+    const u16x2 V = as_u16x2(v), U = as_u16x2(u), D = as_u16x2(d), Lp = as_u16x2(l), Rp = as_u16x2(r), T = as_u16x2(th2);
+    const u16x2 A = __builtin_elementwise_max(__builtin_elementwise_min(U, D), __builtin_elementwise_min(Lp, Rp));
+    const u16x2 B = __builtin_elementwise_min(__builtin_elementwise_max(U, D), __builtin_elementwise_max(Lp, Rp));
+    const u16x2 t1 = (A + T) - V;  // negative iff A + th < v
+    const u16x2 t2 = (V + T) - B;  // negative iff v + th < B
+    return (as_u32(t1) | as_u32(t2)) & 0x80008000u;
+}
+
 // One wave per cell.  ROI -> LDS (aligned 32-bit loads), then a cascade:
-//   1. cheap necessary test on two opposite ring pairs at the lower threshold;
-//      survivors queued in raster order,
-//   2. full strength for queued pixels; pixels above the lower threshold are
-//      written to the strength plane and re-queued (still raster order),
-//   3. non-max suppression over the queue at iniTh, then at minTh when nothing
-//      survived (the reference's per-cell fallback), survivors written in
-//      raster order to the cell's slot range.
-// A single wave executes LDS operations in program order, so the phases need
-// no workgroup barrier beyond the compiler-level ordering of __syncthreads().
+//   1. the pair test above on 4 pixels per lane (one LDS word and its four neighbour
+//      words); survivors queued in raster order as (y << 8 | x),
+//   2. full strength for queued pixels; pixels above the threshold are written to the
+//      strength plane and re-queued (still raster order),
+//   3. non-max suppression over the queue; survivors written in raster order to the
+//      cell's slot range.
+// The cascade runs at iniTh and is repeated at minTh only when nothing survived (the
+// reference's per-cell fallback).  A single wave executes LDS operations in program order,
+// so the phases need no workgroup barrier beyond the compiler-level ordering of
+// __syncthreads().
 __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligned, const u8* __restrict__ pyr,
-                                              u32* __restrict__ cellCount, u32* __restrict__ slots,
-                                              int iniTh, int minTh) {
+                                              const FastCell* __restrict__ cells, u32* __restrict__ cellCount,
+                                              u32* __restrict__ slots, int iniTh, int minTh) {
     extern __shared__ __align__(16) u8 lds[];
     u8* roi = lds;
     u8* plane = lds + g.fastPlaneOff;
@@ -388,75 +475,95 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
     // XCD, so the halo rows and cache lines that neighbouring cells share come from its L2.
     const int f = blockIdx.x;
     const int cell = blockIdx.y;
-    int l = 0;
-    while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellBase) l++;
-    const LevelGeom& L = g.lv[l];
-    const int c = cell - L.cellBase;
-    const int ci = c / L.nCols, cj = c - ci * L.nCols;
     const int lane = threadIdx.x;
+    const FastCell C = cells[cell];
+    const int l = C.w[0] & 255, rw = (C.w[0] >> 8) & 255, rh = (C.w[0] >> 16) & 255;
+    const int iniX = C.w[1] & 0xffff, iniY = C.w[1] >> 16;
+    const int cellCap = C.w[3] & 0xffff;
     u32* cnt = cellCount + (i64)f * g.totalCells + cell;
-    const int maxBX = L.w - MIN_BORDER, maxBY = L.h - MIN_BORDER;
-    const int iniX = MIN_BORDER + cj * L.wCell, iniY = MIN_BORDER + ci * L.hCell;
-    const int rw = min(iniX + L.wCell + 6, maxBX) - iniX;
-    const int rh = min(iniY + L.hCell + 6, maxBY) - iniY;
     if (rw < 7 || rh < 7) {
         if (lane == 0) *cnt = 0;
         return;
     }
     const int RP = g.fastRoiPitch;
     const ImgRef im = level_image(g, l, img0, pyr);
-    int xo = 0;
+    const int iw = rw - 6, ih = rh - 6, pw = iw + 2;
+    int xo = 0, nk;
+    u32 mgk;
     if (l > 0 || img0Aligned) {
         const int xa = iniX & ~3;
         xo = iniX - xa;
-        const int nW = (xo + rw + 3) >> 2;
-        const u32 mg = div_magic(nW);
+        const int nW = (int)C.w[7];
+        const u32 mg = C.w[5];
+        nk = (int)(C.w[3] >> 16);
+        mgk = C.w[6];
         const u8* srow = im.base + (i64)f * im.frameStride + (i64)iniY * im.pitch + xa;
         for (int i = lane; i < nW * rh; i += 64) {
             const int y = fastdiv(i, nW, mg), wd = i - y * nW;
-            ((u32*)(roi + y * RP))[wd] = *(const u32*)(srow + (i64)y * im.pitch + 4 * wd);
+            ((u32*)(roi + y * RP))[wd] = *(const u32*)(srow + mul24((u32)y, (u32)im.pitch) + 4 * wd);
         }
     } else {
         const u32 mg = div_magic(rw);
+        nk = ((3 + iw - 1) >> 2) + 1;
+        mgk = div_magic(nk);
         const u8* srow = im.base + (i64)f * im.frameStride + (i64)iniY * im.pitch + iniX;
         for (int i = lane; i < rw * rh; i += 64) {
             const int y = fastdiv(i, rw, mg), x = i - y * rw;
-            roi[y * RP + x] = srow[(i64)y * im.pitch + x];
+            roi[y * RP + x] = srow[mul24((u32)y, (u32)im.pitch) + x];
         }
     }
+    const int X0 = xo + 3, k0 = X0 >> 2;  // interior pixel x sits at byte X0 + x of its ROI row
     const u8* R = roi + xo;
-    const int iw = rw - 6, ih = rh - 6, pw = iw + 2, npx = iw * ih;
-    const u32 mgw = div_magic(iw);
-    for (int i = lane; i < (pw * (ih + 2) + 3) / 4; i += 64) ((u32*)plane)[i] = 0;
+    const int nPlaneWords = (pw * (ih + 2) + 3) >> 2;
+    for (int i = lane; i < nPlaneWords; i += 64) ((u32*)plane)[i] = 0;
     __syncthreads();
 
-    u32* out = slots + (i64)f * g.totalSlots + L.slotBase + (i64)c * L.cellCap;
-    const int gx0 = cj * L.wCell + 3, gy0 = ci * L.hCell + 3;  // relative to the detection origin
+    u32* out = slots + (i64)f * g.totalSlots + C.w[2];
+    const int gx0 = C.w[4] & 0xffff, gy0 = C.w[4] >> 16;  // relative to the detection origin
+    const int items = ih * nk;
     int total = 0;
-    // The whole cascade runs at iniTh first: pixels whose strength is at most iniTh cannot
-    // influence that result.  Only a cell that ends with no survivor repeats it at minTh.
     for (int pass = 0; pass < 2; pass++) {
         const int th = min(max(pass == 0 ? iniTh : minTh, 0), 255);
+        const u32 th2 = (u32)th | ((u32)th << 16);
         if (pass == 1) {
-            for (int i = lane; i < (pw * (ih + 2) + 3) / 4; i += 64) ((u32*)plane)[i] = 0;
+            for (int i = lane; i < nPlaneWords; i += 64) ((u32*)plane)[i] = 0;
             __syncthreads();
         }
         int n1 = 0;
-        for (int base = 0; base < npx; base += 64) {
-            const int i = base + lane;
-            bool pass1 = false;
-            if (i < npx) {
-                const int y = fastdiv(i, iw, mgw), x = i - y * iw;
-                const u8* p = R + (y + 3) * RP + x + 3;
-                const int v = p[0];
-                const int d0 = v - p[3 * RP], d8 = v - p[-3 * RP], d4 = v - p[3], d12 = v - p[-3];
-                const int dk = min(max(d0, d8), max(d4, d12));
-                const int br = max(min(d0, d8), min(d4, d12));
-                pass1 = dk > th || br < -th;
+        for (int base = 0; base < items; base += 64) {
+            const int it = base + lane;
+            u32 m4 = 0;
+            int y = 0, xb = 0;
+            if (it < items) {
+                y = fastdiv(it, nk, mgk);
+                const int k = k0 + (it - y * nk);
+                const u32* rc = (const u32*)(roi + (y + 3) * RP) + k;
+                const u32 Cw = rc[0], Lw = rc[-1], Rw = rc[1];
+                const u32 Uw = ((const u32*)(roi + y * RP))[k], Dw = ((const u32*)(roi + (y + 6) * RP))[k];
+                const u32 Rt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);  // pixels x + 3
+                const u32 Lf = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels x - 3
+                const u32 M = 0x00FF00FFu;
+                const u32 e = pair_test2(Cw & M, Uw & M, Dw & M, Lf & M, Rt & M, th2);
+                const u32 o = pair_test2((Cw >> 8) & M, (Uw >> 8) & M, (Dw >> 8) & M, (Lf >> 8) & M, (Rt >> 8) & M, th2);
+                const u32 mm = (e >> 1) | o;  // bits 14, 15, 30, 31 = pixels 0, 1, 2, 3 of the word
+                m4 = ((mm >> 14) & 3u) | ((mm >> 28) & 12u);
+                xb = 4 * k - X0;  // interior x of the word's first pixel
+                const int lo = max(-xb, 0), hi = min(iw - xb, 4);
+                m4 &= (15u << lo) & (15u >> (4 - hi));
             }
-            int tot;
-            const int off = wave_excl_count(pass1, &tot);
-            if (pass1) queue[n1 + off] = (u16)i;
+            // ordered compaction: lanes are in raster order and so are the pixels of a word
+            const int c = __popc(m4);
+            const u64 b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
+            const int pre = __builtin_amdgcn_mbcnt_hi((u32)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b0, 0)) +
+                            2 * __builtin_amdgcn_mbcnt_hi((u32)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b1, 0)) +
+                            4 * __builtin_amdgcn_mbcnt_hi((u32)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b2, 0));
+            const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+            const int ent = (y << 8) + xb;  // + pixel index in the word = (y << 8 | x) for valid pixels
+            u16* qp = queue + n1 + pre;
+            if (m4 & 1u) *qp++ = (u16)ent;
+            if (m4 & 2u) *qp++ = (u16)(ent + 1);
+            if (m4 & 4u) *qp++ = (u16)(ent + 2);
+            if (m4 & 8u) *qp = (u16)(ent + 3);
             n1 += tot;
         }
         __syncthreads();
@@ -464,10 +571,10 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
         for (int base = 0; base < n1; base += 64) {
             const int wi = base + lane;
             bool corner = false;
-            int i = 0;
+            u32 ent = 0;
             if (wi < n1) {
-                i = queue[wi];
-                const int y = fastdiv(i, iw, mgw), x = i - y * iw;
+                ent = queue[wi];
+                const int y = ent >> 8, x = ent & 255;
                 const u8* p = R + (y + 3) * RP + x + 3;
                 const int v = p[0];
                 int d[16];
@@ -496,7 +603,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
             int tot;
             const int off = wave_excl_count(corner, &tot);
             __syncthreads();  // every lane has read its queue entry before the in-place compaction writes
-            if (corner) queue[n2 + off] = (u16)i;
+            if (corner) queue[n2 + off] = (u16)ent;
             n2 += tot;
         }
         __syncthreads();
@@ -507,9 +614,9 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
             bool keep = false;
             int x = 0, y = 0, s = 0;
             if (wi < n2) {
-                const int i = queue[wi];
-                y = fastdiv(i, iw, mgw);
-                x = i - y * iw;
+                const u32 ent = queue[wi];
+                y = ent >> 8;
+                x = ent & 255;
                 const u8* q = &plane[(y + 1) * pw + x + 1];
                 s = (int)q[0] - 1;
 #define SC(o) max((int)q[o] - 1, 0)
@@ -519,12 +626,12 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
             }
             int tot;
             const int off = wave_excl_count(keep, &tot);
-            if (keep && total + off < L.cellCap) out[total + off] = ORBX_PACK(gx0 + x, gy0 + y, s);
+            if (keep && total + off < cellCap) out[total + off] = ORBX_PACK(gx0 + x, gy0 + y, s);
             total += tot;
         }
         if (total > 0) break;
     }
-    if (lane == 0) *cnt = (u32)min(total, L.cellCap);
+    if (lane == 0) *cnt = (u32)min(total, cellCap);
 }
 
 // ------------------------------------------------------------------ quadtree
@@ -1099,6 +1206,8 @@ struct orbx_handle {
     bool geomValid = false;
     size_t qtLds = 0;
     ResizeTap* dTaps = nullptr;  // x taps then y taps for each level >= 1
+    FastCell* dCells = nullptr;  // one record per FAST cell, all levels
+    size_t cellsCap = 0;
     size_t tapsCap = 0;
     size_t tapXOff[ORBX_MAX_LEVELS], tapYOff[ORBX_MAX_LEVELS];
     bool resizeStreamOk[ORBX_MAX_LEVELS];  // taps of a 4-pixel group fit the three-word window
@@ -1366,6 +1475,45 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
         ORBX_HIP_CHECK(hipMemcpy(h->dTaps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
     }
+    // FAST cell records (reference src/ORBextractor.cc:799-817 for the ROI bounds)
+    std::vector<FastCell> cells((size_t)g.totalCells);
+    memset(cells.data(), 0, cells.size() * sizeof(FastCell));
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom& L = g.lv[l];
+        const int maxBX = L.w - MIN_BORDER, maxBY = L.h - MIN_BORDER;
+        for (int c = 0; c < L.nCells; c++) {
+            const int ci = c / L.nCols, cj = c - ci * L.nCols;
+            const int iniX = MIN_BORDER + cj * L.wCell, iniY = MIN_BORDER + ci * L.hCell;
+            const int rw = std::max(std::min(iniX + L.wCell + 6, maxBX) - iniX, 0);
+            const int rh = std::max(std::min(iniY + L.hCell + 6, maxBY) - iniY, 0);
+            const int xo = iniX & 3, X0 = xo + 3, iw = std::max(rw - 6, 1);
+            const int nW = (xo + rw + 3) >> 2;
+            const int nk = ((X0 + iw - 1) >> 2) - (X0 >> 2) + 1;
+            auto magic = [](int d) { return d <= 1 ? 0u : (u32)(0x100000000ull / (u32)d) + 1u; };
+            FastCell& F = cells[(size_t)L.cellBase + c];
+            F.w[0] = (u32)l | ((u32)rw << 8) | ((u32)rh << 16);
+            F.w[1] = (u32)iniX | ((u32)iniY << 16);
+            F.w[2] = (u32)(L.slotBase + c * L.cellCap);
+            F.w[3] = (u32)L.cellCap | ((u32)nk << 16);
+            F.w[4] = (u32)(cj * L.wCell + 3) | ((u32)(ci * L.hCell + 3) << 16);
+            F.w[5] = magic(nW);
+            F.w[6] = magic(nk);
+            F.w[7] = (u32)nW;
+            if (L.cellCap > 0xffff || rw > 255 || rh > 255) {
+                orbx_set_error("internal: cell record overflow");
+                return ORBX_ERR_UNSUPPORTED;
+            }
+        }
+    }
+    if (cells.size() > h->cellsCap) {
+        free_dev(h->dCells);
+        h->dCells = nullptr;
+        h->cellsCap = 0;
+        ORBX_HIP_CHECK(hipMalloc((void**)&h->dCells, cells.size() * sizeof(FastCell)));
+        h->cellsCap = cells.size();
+    }
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    ORBX_HIP_CHECK(hipMemcpy(h->dCells, cells.data(), cells.size() * sizeof(FastCell), hipMemcpyHostToDevice));
     h->geomValid = true;
     h->scratchSig = 0;  // force a scratch size check
     return ORBX_OK;
@@ -1458,12 +1606,18 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         // Level 0 is the caller's buffer: the streaming kernel reads it as aligned 32-bit
         // words, so it needs 4-byte aligned rows and a width that is a multiple of 4.
         const bool aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0 &&
-                              (g.w & 3) == 0 && img0.pitch >= g.w;
+                              (g.w & 3) == 0 && img0.pitch >= g.w && g.h >= 4 && g.w >= 4;
         const int first = aligned0 ? 0 : 1;
         if (!aligned0) {
             dim3 grid(g.lv[0].blurTiles, n, 1), block(256, 1, 1);
             hipLaunchKernelGGL(k_blur, grid, block, 0, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
                                h->gaussK[1], h->gaussK[2], h->gaussK[3], 0);
+        }
+        for (int l = 1; l < g.nlevels; l++) {
+            if (g.lv[l].h >= 4 && g.lv[l].w >= 4) continue;
+            dim3 grid(g.lv[l].blurTiles, n, 1), block(256, 1, 1);
+            hipLaunchKernelGGL(k_blur, grid, block, 0, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                               h->gaussK[1], h->gaussK[2], h->gaussK[3], g.lv[l].blurTileBase);
         }
         const int itemBegin = g.lv[first].blurItemBase;
         if (first < g.nlevels && g.totalBlurItems > itemBegin) {
@@ -1483,7 +1637,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         const int aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0;
         dim3 grid(n, g.totalCells, 1), block(64, 1, 1);
         hipLaunchKernelGGL(k_fast, grid, block, g.fastLdsBytes, st, g, img0, aligned0, (const u8*)h->dPyr,
-                           h->dCellCount, h->dSlots, h->cfg.ini_th_fast, h->cfg.min_th_fast);
+                           (const FastCell*)h->dCells, h->dCellCount, h->dSlots, h->cfg.ini_th_fast, h->cfg.min_th_fast);
     }
     {
         StageTimer t(h, ORBX_STAGE_QUADTREE);
@@ -1577,7 +1731,7 @@ void orbx_destroy(orbx_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_dev(h->dPyr); free_dev(h->dBlur); free_dev(h->dCellCount); free_dev(h->dSlots);
     free_dev(h->dKeyPacked); free_dev(h->dKeyNode); free_dev(h->dSel); free_dev(h->dSelCount);
-    free_dev(h->dErr); free_dev(h->dTaps); free_dev(h->dImgStage); free_dev(h->dKpStage);
+    free_dev(h->dErr); free_dev(h->dTaps); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dKpStage);
     free_dev(h->dDescStage); free_dev(h->dNStage);
     for (int s = 0; s < ORBX_STAGE_COUNT; s++)
         for (auto& e : h->prof.ev[s]) {
