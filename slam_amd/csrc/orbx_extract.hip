@@ -440,6 +440,9 @@ __device__ __forceinline__ u32 as_u32(u16x2 v) {
     return r;
 }
 
+// Bytes 1 and 3 of a word as two 16-bit values (one packed 16-bit shift).
+__device__ __forceinline__ u32 odd_bytes(u32 w) { return as_u32(as_u16x2(w) >> (u16x2)(8)); }
+
 // Necessary condition for a FAST-9 corner on two pixels at once (16-bit halves): with
 // u/d/l/r the ring pixels 3 above, below, left and right of v, a 9-arc holds one pixel of
 // each opposite pair, so   max(min(u,d), min(l,r)) + th < v   (darker arc)   or
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                 const u32 Lf = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels x - 3
                 const u32 M = 0x00FF00FFu;
                 const u32 e = pair_test2(Cw & M, Uw & M, Dw & M, Lf & M, Rt & M, th2);
-                const u32 o = pair_test2((Cw >> 8) & M, (Uw >> 8) & M, (Dw >> 8) & M, (Lf >> 8) & M, (Rt >> 8) & M, th2);
+                const u32 o = pair_test2(odd_bytes(Cw), odd_bytes(Uw), odd_bytes(Dw), odd_bytes(Lf), odd_bytes(Rt), th2);
                 const u32 mm = (e >> 1) | o;  // bits 14, 15, 30, 31 = pixels 0, 1, 2, 3 of the word
                 m4 = ((mm >> 14) & 3u) | ((mm >> 28) & 12u);
                 xb = 4 * k - X0;  // interior x of the word's first pixel
@@ -1068,89 +1071,156 @@ __global__ void k_debug_atan2(const float* y, const float* x, float* out, int n)
     if (i < n) out[i] = fast_atan2_deg(y[i], x[i]);
 }
 
-#define DESC_KPW 4  // keypoints per wave
+#define DESC_KPW 8  // keypoints per wave
 
-// Orientation + descriptor.  Each wave handles DESC_KPW keypoint slots in turn.
-// Orientation: the radius-15 disc is read as 248 unaligned 32-bit words and
-// reduced with two v_dot4_u32_u8 per word (weights u+15 and membership).
-// Descriptor: 256 steered tests on the blurred level, one bit per lane and
-// round, gathered with wave ballots.
+__device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Orientation + descriptor, DESC_KPW keypoints per wave.
+//   A. moments: the radius-15 disc of every keypoint is read as 248 unaligned 32-bit words
+//      (4 per lane, all keypoints' loads in flight together) and reduced with two
+//      v_dot4_u32_u8 per word (weights u+15 and membership);
+//   B. the 16 partial sums of a lane (m10, m01 of 8 keypoints) are summed over the wave by a
+//      halving exchange (17 cross-lane moves instead of 96) that leaves keypoint j's sums in
+//      lanes 8j..8j+7, where fastAtan2 and the steering sine/cosine are evaluated once for
+//      all keypoints;
+//   C. per keypoint: 256 steered tests on the blurred level, one bit per lane and round,
+//      gathered with wave ballots.
 __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8* __restrict__ pyr,
                                                    const u8* __restrict__ blur,
                                                    const u32* __restrict__ sel,
                                                    const int* __restrict__ selCount,
                                                    orbx_keypoint* kps, u8* desc, int cap, int* nOut,
                                                    int* errFlag) {
-    __shared__ DescribeTables T;
-    {
-        const u32* srcT = (const u32*)&d_tables;
-        u32* dstT = (u32*)&T;
-        for (int i = threadIdx.x; i < (int)(sizeof(DescribeTables) / 4); i += 256) dstT[i] = srcT[i];
-    }
-    __syncthreads();
     const int f = blockIdx.x;  // frame first: one XCD per frame
     const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int* sc = selCount + (i64)f * ORBX_MAX_LEVELS;
     int cum[ORBX_MAX_LEVELS + 1];
     cum[0] = 0;
 #pragma unroll
     for (int k = 0; k < ORBX_MAX_LEVELS; k++) cum[k + 1] = cum[k] + (k < g.nlevels ? sc[k] : 0);
-    const int total = cum[ORBX_MAX_LEVELS];
-    const int sBase = (blockIdx.y * 4 + (threadIdx.x >> 6)) * DESC_KPW;
+    const int total = min(cum[ORBX_MAX_LEVELS], cap);
+    const int sBase = (blockIdx.y * 4 + wv) * DESC_KPW;
     if (sBase == 0 && lane == 0) {
-        nOut[f] = min(total, cap);
-        if (total > cap) *errFlag = 2;
+        nOut[f] = total;
+        if (cum[ORBX_MAX_LEVELS] > cap) *errFlag = 2;
     }
-    const float factorPI = (float)(M_PI / 180.f);
-    for (int kk = 0; kk < DESC_KPW; kk++) {
-        const int s = sBase + kk;
-        if (s >= total || s >= cap) return;
+    if (sBase >= total) return;
+
+    // tables: this lane's 4 disc words and its 4 tests (one per round), kept in registers
+    u32 wU[4], wM[4];
+    float px0[4], py0[4], px1[4], py1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int slot = min(lane + 64 * i, 247);
+        wU[i] = lane + 64 * i < 248 ? d_tables.patchU[slot] : 0u;
+        wM[i] = lane + 64 * i < 248 ? d_tables.patchM[slot] : 0u;
+        const int pw = (int)d_tables.pattern[i * 64 + lane];
+        px0[i] = (float)((pw << 24) >> 24);
+        py0[i] = (float)((pw << 16) >> 24);
+        px1[i] = (float)((pw << 8) >> 24);
+        py1[i] = (float)(pw >> 24);
+    }
+
+    // lane j < DESC_KPW looks up keypoint sBase + j (slots past the end repeat the first one)
+    int myL = 0, myX = 0, myY = 0, myR = 0;
+    {
+        const int s = (lane < DESC_KPW && sBase + lane < total) ? sBase + lane : sBase;
         int l = 0;
 #pragma unroll
         for (int k = 1; k < ORBX_MAX_LEVELS; k++) l += (s >= cum[k]) ? 1 : 0;
         l = min(l, g.nlevels - 1);
-        const int idx = s - cum[l];
-        const LevelGeom& L = g.lv[l];
-        const u32 key = sel[(i64)f * g.totalSel + L.selBase + idx];
-        const int x = ORBX_PX(key), y = ORBX_PY(key);
-
-        const ImgRef im = level_image(g, l, img0, pyr);
-        const u8* center = im.base + (i64)f * im.frameStride + (i64)y * im.pitch + x;
-        int m10 = 0, m01 = 0;
+        int c = 0, selBase = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int slot = lane + 64 * i;
-            if (slot < 248) {
+        for (int k = 0; k < ORBX_MAX_LEVELS; k++) {
+            if (k < g.nlevels && l == k) {
+                c = cum[k];
+                selBase = g.lv[k].selBase;
+            }
+        }
+        const u32 key = sel[(i64)f * g.totalSel + selBase + (s - c)];
+        myL = l;
+        myX = ORBX_PX(key);
+        myY = ORBX_PY(key);
+        myR = ORBX_PR(key);
+    }
+
+    // A: moments
+    int V[2 * DESC_KPW];
+    {
+        u32 px[DESC_KPW][4];
+#pragma unroll
+        for (int j = 0; j < DESC_KPW; j++) {
+            const int l = readlane_i(myL, j), x = readlane_i(myX, j), y = readlane_i(myY, j);
+            const ImgRef im = level_image(g, l, img0, pyr);
+            const u8* center = im.base + (i64)f * im.frameStride + (i64)y * im.pitch + x;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int slot = min(lane + 64 * i, 247);
                 const int v = (slot >> 3) - 15, u0 = (slot & 7) * 4 - 16;
-                u32 px;
-                __builtin_memcpy(&px, center + (i64)v * im.pitch + u0, 4);
-                const int D = (int)__builtin_amdgcn_udot4(px, T.patchU[slot], 0u, false);
-                const int S = (int)__builtin_amdgcn_udot4(px, T.patchM[slot], 0u, false);
-                m10 += D - 15 * S;
-                m01 += v * S;
+                __builtin_memcpy(&px[j][i], center + v * im.pitch + u0, 4);
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o);
-            m01 += __shfl_xor(m01, o);
+        for (int j = 0; j < DESC_KPW; j++) {
+            int m10 = 0, m01 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int v = (min(lane + 64 * i, 247) >> 3) - 15;
+                const int D = (int)__builtin_amdgcn_udot4(px[j][i], wU[i], 0u, false);
+                const int S = (int)__builtin_amdgcn_udot4(px[j][i], wM[i], 0u, false);
+                m10 += D - 15 * S;
+                m01 += v * S;
+            }
+            V[2 * j] = m10;
+            V[2 * j + 1] = m01;
         }
-        const float angle = fast_atan2_deg((float)m01, (float)m10);
-        float a, b;
-        steer_sincos(__fmul_rn(angle, factorPI), &b, &a);
-        const u8* bc = blur + (i64)f * g.blurFrameBytes + L.blurOff + (i64)y * L.blurPitch + x;
+    }
+    // B: halving exchange.  After the steps with lane distance 32, 16, 8, 4 a lane holds the
+    // sum over 4 lanes... of value index (lane >> 2) & 15; distances 2 and 1 finish the sum.
+    {
+#pragma unroll
+        for (int half = DESC_KPW, dist = 32; half >= 1; half >>= 1, dist >>= 1) {
+            const bool up = (lane & dist) != 0;
+#pragma unroll
+            for (int t = 0; t < half; t++) {
+                const int keep = up ? V[t + half] : V[t];
+                const int send = up ? V[t] : V[t + half];
+                V[t] = keep + __shfl_xor(send, dist);
+            }
+        }
+        V[0] += __shfl_xor(V[0], 2);
+        V[0] += __shfl_xor(V[0], 1);
+    }
+    // lanes 8j..8j+3 hold m10 of keypoint j, lanes 8j+4..8j+7 its m01
+    const int other = __shfl_xor(V[0], 4);
+    const int m10 = (lane & 4) ? other : V[0], m01 = (lane & 4) ? V[0] : other;
+    const float factorPI = (float)(M_PI / 180.f);
+    const float angleV = fast_atan2_deg((float)m01, (float)m10);
+    float aV, bV;
+    steer_sincos(__fmul_rn(angleV, factorPI), &bV, &aV);
+
+    // C: descriptors and keypoint records
+#pragma unroll 2
+    for (int j = 0; j < DESC_KPW; j++) {
+        const int s = sBase + j;
+        if (s >= total) break;
+        const int l = readlane_i(myL, j), x = readlane_i(myX, j), y = readlane_i(myY, j), resp = readlane_i(myR, j);
+        const float a = readlane_f(aV, 8 * j), b = readlane_f(bV, 8 * j), angle = readlane_f(angleV, 8 * j);
+        const int blurPitch = g.lv[l].blurPitch;
+        const u8* bc = blur + (i64)f * g.blurFrameBytes + g.lv[l].blurOff + (i64)y * blurPitch + x;
         u32 word = 0;  // lane k < 8 ends up holding descriptor bytes 4k..4k+3
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int pw = (int)T.pattern[r * 64 + lane];
-            const float x0 = (float)((pw << 24) >> 24), y0 = (float)((pw << 16) >> 24);
-            const float x1 = (float)((pw << 8) >> 24), y1 = (float)(pw >> 24);
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-            const int t0 = bc[r0 * L.blurPitch + c0];
-            const int t1 = bc[r1 * L.blurPitch + c1];
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)));
+            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)));
+            const int t0 = bc[r0 * blurPitch + c0];
+            const int t1 = bc[r1 * blurPitch + c1];
             const u64 bits = __ballot(t0 < t1);
             if (lane == 2 * r) word = (u32)bits;
             if (lane == 2 * r + 1) word = (u32)(bits >> 32);
@@ -1159,15 +1229,16 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
         if (lane < 8) ((u32*)(desc + o * 32))[lane] = word;
         // the 7 dwords of the 28-byte keypoint, one per lane
         float kx = (float)x, ky = (float)y;
+        const float scale = g.lv[l].scale, kpSize = g.lv[l].kpSize;
         if (l != 0) {
-            kx = __fmul_rn(kx, L.scale);
-            ky = __fmul_rn(ky, L.scale);
+            kx = __fmul_rn(kx, scale);
+            ky = __fmul_rn(ky, scale);
         }
         u32 kv = __float_as_uint(kx);
         kv = lane == 1 ? __float_as_uint(ky) : kv;
-        kv = lane == 2 ? __float_as_uint(L.kpSize) : kv;
+        kv = lane == 2 ? __float_as_uint(kpSize) : kv;
         kv = lane == 3 ? __float_as_uint(angle) : kv;
-        kv = lane == 4 ? __float_as_uint((float)ORBX_PR(key)) : kv;
+        kv = lane == 4 ? __float_as_uint((float)resp) : kv;
         kv = lane == 5 ? (u32)l : kv;
         kv = lane == 6 ? 0xFFFFFFFFu : kv;
         if (lane < 7) ((u32*)(kps + o))[lane] = kv;
