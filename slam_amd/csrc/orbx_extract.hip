@@ -85,6 +85,20 @@ __device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) {
     return r;
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u16x2 as_u16x2(u32 v) {
+    u16x2 r;
+    __builtin_memcpy(&r, &v, 4);
+    return r;
+}
+__device__ __forceinline__ u32 as_u32(u16x2 v) {
+    u32 r;
+    __builtin_memcpy(&r, &v, 4);
+    return r;
+}
+
 // ------------------------------------------------------------------ resize
 struct ResizeTap {
     u16 i0, i1;  // source indices (already clamped)
@@ -121,17 +135,23 @@ __global__ __launch_bounds__(256) void k_resize(ImgRef src, u8* dst, int dPitch,
 
 #define RESIZE_BH 32  // destination rows per band of the streaming kernel
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+#define RESIZE_PF 4  // source rows fetched ahead
 
-// Streaming form of the same arithmetic.  A lane owns 4 destination columns
-// and walks down a band of rows; per source row it loads three aligned words
-// that cover its 4x2 taps, picks each pixel's two bytes with a per-lane byte
-// permutation fixed at start-up, and forms the horizontal sum with one
-// v_dot2_u32_u16.  Requires 4-byte aligned source rows and taps that fit the
-// three-word window (checked on the host; true for scale factors <= 2).
-__global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, u8* dst, int dPitch, i64 dFrame,
+// Streaming form of the same arithmetic.  A lane owns 4 destination columns and walks
+// down the SOURCE rows of a band of destination rows.  Per source row it loads three
+// aligned words, shifts them into an 8-byte window that starts at its first tap
+// (v_alignbyte_b32), picks each pixel's two bytes with a per-lane byte permutation fixed at
+// start-up and forms the horizontal sum with one v_dot2_u32_u16; the sums of the previous
+// source row stay in registers, so every source row is read and summed once.  A
+// destination row is produced when the walk reaches its second source row (a table indexed
+// by source row says which, so the walk has no data-dependent loads).  Source rows and
+// table entries are fetched RESIZE_PF rows ahead of their use.  Requires 4-byte aligned source rows, taps
+// within 8 bytes of the group's first tap, second tap = first or first + 1, and row taps
+// that never step backwards (checked on the host; true for scale factors 1 < s <= 1.6).
+__global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, int sh, u8* dst, int dPitch, i64 dFrame,
                                                         int dw, int dh, const ResizeTap* __restrict__ xt,
-                                                        const ResizeTap* __restrict__ yt) {
+                                                        const ResizeTap* __restrict__ yt,
+                                                        const ResizeTap* __restrict__ st) {
     const int G = (dw + 3) >> 2;
     const int nb = (dh + RESIZE_BH - 1) / RESIZE_BH;
     // blockIdx.x is the frame: blocks are dealt round-robin over the 8 XCDs, so with a batch
@@ -143,49 +163,93 @@ __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, 
     const int f = blockIdx.x;
     const ResizeTap t0 = xt[min(4 * gx, dw - 1)];
     const int wb = t0.i0 >> 2;
+    const u32 shift = t0.i0 & 3;
     u32 sel[4], coef[4];
-    bool hiPair[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const ResizeTap t = xt[min(4 * gx + j, dw - 1)];
-        const int o0 = t.i0 - 4 * wb, o1 = t.i1 - 4 * wb;
-        const int k = o0 >= 4 ? 1 : 0;
-        hiPair[j] = k != 0;
+        const u32 d0 = t.i0 - t0.i0, d1 = t.i1 - t0.i0;
         // bytes: [tap0, 0, tap1, 0]; selector 12 yields a zero byte
-        sel[j] = (u32)(o0 - 4 * k) | (12u << 8) | ((u32)(o1 - 4 * k) << 16) | (12u << 24);
+        sel[j] = d0 | (12u << 8) | (d1 << 16) | (12u << 24);
         coef[j] = (u32)(u16)t.c0 | ((u32)(u16)t.c1 << 16);
     }
     const int wA = min(wb, maxWord), wB = min(wb + 1, maxWord), wC = min(wb + 2, maxWord);
     const u8* sbase = src.base + (i64)f * src.frameStride;
+    const u32 sPitch = (u32)src.pitch, dPitchU = (u32)dPitch;
     u8* dbase = dst + (i64)f * dFrame + 4 * gx;
     const int y0 = band * RESIZE_BH, y1 = min(y0 + RESIZE_BH, dh);
-    auto hsum = [&](const u32* row, u32* t) {
-        const u32 A = row[wA], B = row[wB], C = row[wC];
+
+    struct Raw {
+        u32 a, b, c;
+    };
+    auto fetch = [&](int s) {
+        const u32* row = (const u32*)(sbase + mul24((u32)min(s, sh - 1), sPitch));
+        Raw r;
+        r.a = row[wA];
+        r.b = row[wB];
+        r.c = row[wC];
+        return r;
+    };
+    // horizontal sums of one source row, already shifted right by 4 as the vertical step wants
+    auto hsum = [&](const Raw& r, u32* t) {
+        const u32 W0 = __builtin_amdgcn_alignbyte(r.b, r.a, shift), W1 = __builtin_amdgcn_alignbyte(r.c, r.b, shift);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const u32 lo = hiPair[j] ? B : A, hi = hiPair[j] ? C : B;
-            const u32 pr = __builtin_amdgcn_perm(hi, lo, sel[j]);
-            u16x2 pv, cv;
-            __builtin_memcpy(&pv, &pr, 4);
-            __builtin_memcpy(&cv, &coef[j], 4);
-            t[j] = __builtin_amdgcn_udot2(pv, cv, 0u, false);
+            const u32 pr = __builtin_amdgcn_perm(W1, W0, sel[j]);
+            t[j] = __builtin_amdgcn_udot2(as_u16x2(pr), as_u16x2(coef[j]), 0u, false) >> 4;
         }
     };
-#pragma unroll 4
-    for (int y = y0; y < y1; y++) {
-        const ResizeTap ty = yt[y];
-        u32 ta[4], tb[4];
-        hsum((const u32*)(sbase + mul24(ty.i0, (u32)src.pitch)), ta);
-        hsum((const u32*)(sbase + mul24(ty.i1, (u32)src.pitch)), tb);
-        // weights are 0..2048 and t >> 4 < 2^15
-        const u32 b0 = (u32)(int)ty.c0, b1 = (u32)(int)ty.c1;
-        u32 out = 0;
+
+    // st[2 * s + e], e = 0, 1: the destination rows whose second tap is source row s, as
+    // {i0 = destination row or 0xFFFF, i1 = 1 when both taps are row s, c0, c1}
+    int s = yt[y0].i0;                // first source row of the band
+    const int sLast = yt[y1 - 1].i1;  // last one
+    u32 prev[4] = {0, 0, 0, 0}, cur[4];
+    Raw rawCur[RESIZE_PF];
+    uint4 tabCur[RESIZE_PF];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const u32 v = ((mul24(b0, ta[j] >> 4) >> 16) + (mul24(b1, tb[j] >> 4) >> 16) + 2u) >> 2;
-            out |= (v & 0xFFu) << (8 * j);
+    for (int k = 0; k < RESIZE_PF; k++) {
+        rawCur[k] = fetch(s + k);
+        tabCur[k] = *(const uint4*)(st + 2 * min(s + k, sh - 1));
+    }
+    while (s <= sLast) {
+        Raw rawNxt[RESIZE_PF];
+        uint4 tabNxt[RESIZE_PF];
+#pragma unroll
+        for (int k = 0; k < RESIZE_PF; k++) {
+            rawNxt[k] = fetch(s + RESIZE_PF + k);
+            tabNxt[k] = *(const uint4*)(st + 2 * min(s + RESIZE_PF + k, sh - 1));
         }
-        *(u32*)(dbase + mul24((u32)y, (u32)dPitch)) = out;
+#pragma unroll
+        for (int k = 0; k < RESIZE_PF; k++) {
+            hsum(rawCur[k], cur);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const u32 w0 = e == 0 ? tabCur[k].x : tabCur[k].z, w1 = e == 0 ? tabCur[k].y : tabCur[k].w;
+                const int y = (int)(w0 & 0xffffu);
+                if (y >= y0 && y < y1 && s + k <= sLast) {
+                    const bool same = (w0 >> 16) != 0;
+                    // weights are 0..2048 and the shifted sums < 2^15: (b * t) >> 16 = mulhi(b << 16, t)
+                    const u32 b0 = w1 << 16, b1 = w1 & 0xffff0000u;
+                    u32 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const u32 ta = same ? cur[j] : prev[j];
+                        v[j] = (__umulhi(b0, ta) + __umulhi(b1, cur[j]) + 2u) >> 2;
+                    }
+                    const u32 out = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                    *(u32*)(dbase + mul24((u32)y, dPitchU)) = out;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) prev[j] = cur[j];
+        }
+        s += RESIZE_PF;
+#pragma unroll
+        for (int k = 0; k < RESIZE_PF; k++) {
+            rawCur[k] = rawNxt[k];
+            tabCur[k] = tabNxt[k];
+        }
     }
 }
 
@@ -427,18 +491,6 @@ struct FastCell {
     u32 w[8];
 };
 
-typedef short i16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ u16x2 as_u16x2(u32 v) {
-    u16x2 r;
-    __builtin_memcpy(&r, &v, 4);
-    return r;
-}
-__device__ __forceinline__ u32 as_u32(u16x2 v) {
-    u32 r;
-    __builtin_memcpy(&r, &v, 4);
-    return r;
-}
 
 // Bytes 1 and 3 of a word as two 16-bit values (one packed 16-bit shift).
 __device__ __forceinline__ u32 odd_bytes(u32 w) { return as_u32(as_u16x2(w) >> (u16x2)(8)); }
@@ -1280,7 +1332,7 @@ struct orbx_handle {
     FastCell* dCells = nullptr;  // one record per FAST cell, all levels
     size_t cellsCap = 0;
     size_t tapsCap = 0;
-    size_t tapXOff[ORBX_MAX_LEVELS], tapYOff[ORBX_MAX_LEVELS];
+    size_t tapXOff[ORBX_MAX_LEVELS], tapYOff[ORBX_MAX_LEVELS], tapSOff[ORBX_MAX_LEVELS];
     bool resizeStreamOk[ORBX_MAX_LEVELS];  // taps of a 4-pixel group fit the three-word window
     // scratch sized for scratchBatch frames of the current geometry
     int scratchBatch = 0;
@@ -1517,7 +1569,8 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
                 const int wb = xt[gx * 4].i0 >> 2;
                 for (int j = 0; j < 4; j++) {
                     const ResizeTap& t = xt[std::min(gx * 4 + j, dw - 1)];
-                    if (t.i0 - 4 * wb > 7 || t.i1 - 4 * wb > 11 || t.i1 < t.i0 || t.i1 - t.i0 > 1) ok = false;
+                    if (t.i0 < xt[gx * 4].i0 || t.i1 - xt[gx * 4].i0 > 7 || t.i1 - 4 * wb > 11 || t.i1 < t.i0 || t.i1 - t.i0 > 1)
+                        ok = false;
                 }
             }
             h->resizeStreamOk[l] = ok;
@@ -1533,6 +1586,42 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
             t.c0 = (short)cv_round_host((1.f - fy) * 2048);
             t.c1 = (short)cv_round_host(fy * 2048);
             taps.push_back(t);
+        }
+        {
+            // the streaming kernel walks source rows forwards: second taps must not decrease,
+            // a first tap is the second tap or the row before it, and weights stay in [0, 2048]
+            const ResizeTap* yt = taps.data() + h->tapYOff[l];
+            for (int dy = 0; dy < dh; dy++) {
+                const ResizeTap& t = yt[dy];
+                if (t.i1 < t.i0 || t.i1 - t.i0 > 1 || (dy > 0 && (t.i1 < yt[dy - 1].i1 || t.i0 < yt[dy - 1].i0)) || t.c0 < 0 ||
+                    t.c1 < 0 || t.c0 > 2048 || t.c1 > 2048)
+                    h->resizeStreamOk[l] = false;
+            }
+            // per source row: the (at most two) destination rows that finish on it; the table
+            // starts on an even entry so that a row's pair is one 16-byte load
+            if (taps.size() & 1) taps.push_back(ResizeTap());
+            h->tapSOff[l] = taps.size();
+            std::vector<ResizeTap> bySrc((size_t)2 * sh);
+            for (size_t i = 0; i < bySrc.size(); i++) {
+                bySrc[i].i0 = 0xFFFF;
+                bySrc[i].i1 = 0;
+                bySrc[i].c0 = bySrc[i].c1 = 0;
+            }
+            yt = taps.data() + h->tapYOff[l];
+            for (int dy = 0; dy < dh; dy++) {
+                const ResizeTap& t = yt[dy];
+                ResizeTap* e = &bySrc[(size_t)2 * t.i1];
+                if (e[0].i0 != 0xFFFF) e++;
+                if (e[0].i0 != 0xFFFF) {
+                    h->resizeStreamOk[l] = false;
+                    break;
+                }
+                e->i0 = (u16)dy;
+                e->i1 = t.i0 == t.i1 ? 1 : 0;
+                e->c0 = t.c0;
+                e->c1 = t.c1;
+            }
+            taps.insert(taps.end(), bySrc.begin(), bySrc.end());
         }
     }
     if (taps.size() > h->tapsCap) {
@@ -1656,9 +1745,9 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             if (srcAligned && h->resizeStreamOk[l]) {
                 const int items = ((L.w + 3) / 4) * ((L.h + RESIZE_BH - 1) / RESIZE_BH);
                 dim3 grid(n, (items + 255) / 256, 1), block(256, 1, 1);
-                hipLaunchKernelGGL(k_resize_stream, grid, block, 0, st, src, src.pitch / 4 - 1, h->dPyr + L.pyrOff,
+                hipLaunchKernelGGL(k_resize_stream, grid, block, 0, st, src, src.pitch / 4 - 1, g.lv[l - 1].h, h->dPyr + L.pyrOff,
                                    L.pyrPitch, g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l],
-                                   h->dTaps + h->tapYOff[l]);
+                                   h->dTaps + h->tapYOff[l], h->dTaps + h->tapSOff[l]);
             } else {
                 dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, n), block(64, 4, 1);
                 hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, h->dPyr + L.pyrOff, L.pyrPitch,
