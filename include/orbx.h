@@ -159,6 +159,7 @@ int orbm_hamming256(const uint8_t* a, const uint8_t* b);
 
 #define ORBM_GRID_COLS 64 /* FRAME_GRID_COLS, reference include/Frame.h:26 */
 #define ORBM_GRID_ROWS 48 /* FRAME_GRID_ROWS, reference include/Frame.h:25 */
+#define ORBM_MAX_LEVELS 16
 
 typedef struct orbm_context orbm_context;
 
@@ -262,6 +263,72 @@ int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm
                               int check_orientation, int32_t* cur_claimed, uint8_t* cur_claimed_obs,
                               int32_t* query_best, int* nmatches, int mem_space);
 
+/* ---- vocabulary-guided searches ----
+ * DBoW2::FeatureVector (a std::map<NodeId, std::vector<unsigned int>>, reference
+ * Thirdparty/DBoW2/DBoW2/FeatureVector.h) flattened to CSR: node_ids strictly ascending (map
+ * order), items[start[i] .. start[i+1]) = the keypoint indices of node i in vector order. */
+typedef struct orbm_feature_vector {
+    int32_t n_nodes;
+    int32_t n_items;
+    const uint32_t* node_ids; /* n_nodes */
+    const int32_t* start;     /* n_nodes + 1 */
+    const uint32_t* items;    /* n_items */
+} orbm_feature_vector;
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, matches) (reference src/ORBmatcher.cc:209-355)
+ * and SearchByBoW(KeyFrame*, KeyFrame*, matches12) (:642-788).  f1/fv1 = the (first)
+ * keyframe, f2/fv2 = the frame or second keyframe.  valid1[i] = keypoint i of f1 holds a map
+ * point that is not bad (:248-251, :684-688); valid2 (NULL = all) = the same for f2 (:700-704).
+ * max_dist is inclusive: TH_LOW (50) for the first overload (:284), TH_LOW - 1 for the second
+ * (:721).  match12[i1] = matched keypoint of f2 or -1 (vpMatches12 by index); match21[i2] =
+ * keypoint of f1 whose map point keypoint i2 of f2 received, or -1 (vpMapPointMatches by
+ * index).  *nmatches = the reference's return value. */
+int orbm_search_by_bow(orbm_context* m, const orbm_frame* f1, const orbm_feature_vector* fv1,
+                       const uint8_t* valid1, const orbm_frame* f2, const orbm_feature_vector* fv2,
+                       const uint8_t* valid2, int max_dist, float nn_ratio, int check_orientation,
+                       int32_t* match12, int32_t* match21, int* nmatches, int mem_space);
+
+/* ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:803-992) from the point
+ * where the epipole (ex, ey) of keyframe 1 in keyframe 2 (:809-818) and the fundamental
+ * matrix are known.  has_mp*[i] = keypoint i already holds a map point (:858, :882);
+ * u_right* = mvuRight; f12: 3x3 row-major, host memory; scale_factors2 / level_sigma2_2:
+ * mvScaleFactors / mvLevelSigma2 of keyframe 2, host memory.  match12 = vMatches12; the pair
+ * list of the reference is its non-negative entries in index order (:984-989). */
+int orbm_search_for_triangulation(orbm_context* m, const orbm_frame* f1, const orbm_feature_vector* fv1,
+                                  const uint8_t* has_mp1, const float* u_right1, const orbm_frame* f2,
+                                  const orbm_feature_vector* fv2, const uint8_t* has_mp2,
+                                  const float* u_right2, const float* f12, float ex, float ey,
+                                  const float* scale_factors2, const float* level_sigma2_2, int nlevels,
+                                  int only_stereo, int check_orientation, int32_t* match12,
+                                  int* nmatches, int mem_space);
+
+/* The candidate loop shared by ORBmatcher::Fuse (reference src/ORBmatcher.cc:1066-1120), its
+ * Sim3 form (:1233-1262) and both directions of SearchBySim3 (:1391-1416, :1462-1489): query i
+ * is a map point already projected to (u, v) with search radius and predicted level (pose
+ * algebra and the culls before the window stay with the caller: valid[i]).  Keypoints of
+ * level-1 or level inside the window compete; the closest descriptor wins, the first in
+ * GetFeaturesInArea order on ties.  chi2_gate = 1 applies Fuse's reprojection test first
+ * (:1085-1111): kf_u_right = mvuRight (NULL = monocular), q_u_right[i] = u - bf*invz,
+ * inv_level_sigma2 = mvInvLevelSigma2 (host memory, nlevels entries).  best_dist[i] = 256 and
+ * best_idx[i] = -1 when nothing qualified; the caller applies TH_LOW / TH_HIGH and the map
+ * point bookkeeping (:1123-1148). */
+int orbm_window_best(orbm_context* m, const orbm_frame* kf, int n, const uint8_t* valid, const float* u,
+                     const float* v, const float* radius, const int32_t* level, const uint8_t* desc,
+                     int chi2_gate, const float* kf_u_right, const float* q_u_right,
+                     const float* inv_level_sigma2, int nlevels, int32_t* best_idx, int32_t* best_dist,
+                     int mem_space);
+
+/* ORBmatcher::SearchBySim3 (reference src/ORBmatcher.cc:1298-1517) from the projections on:
+ * *12 arrays have kf1->n entries (map point of keypoint i of keyframe 1 projected into
+ * keyframe 2; valid12 folds :1355-1385 including vbAlreadyMatched1), *21 arrays kf2->n entries
+ * for the reverse direction.  match12[i1] = keypoint of keyframe 2 when both directions agree
+ * (:1499-1514), else -1; *nfound = the return value. */
+int orbm_search_by_sim3(orbm_context* m, const orbm_frame* kf1, const orbm_frame* kf2,
+                        const uint8_t* valid12, const float* u12, const float* v12, const float* r12,
+                        const int32_t* level12, const uint8_t* mp_desc1, const uint8_t* valid21,
+                        const float* u21, const float* v21, const float* r21, const int32_t* level21,
+                        const uint8_t* mp_desc2, int32_t* match12, int* nfound, int mem_space);
+
 /* Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for a rectified pair.
  * left/right: mvKeys / mDescriptors and mvKeysRight / mDescriptorsRight (the grid bounds of
  * orbm_frame are not read).  pyr_left / pyr_right: mvImagePyramid of the two extractors
@@ -274,7 +341,6 @@ int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm
  * stereo points kept after the median cut (:763-774); asking for it makes the call synchronous.
  * Where the reference would index outside its row table or cut an image window that leaves the
  * pyramid level (cv::Mat range assertion), the keypoint gets no match instead. */
-#define ORBM_MAX_LEVELS 16
 typedef struct orbm_pyramid {
     int32_t nlevels;
     const uint8_t* level[ORBM_MAX_LEVELS];

@@ -506,4 +506,241 @@ void oracle_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* best_i
     }
 }
 
+// Shared body of the two SearchByBoW overloads (reference src/ORBmatcher.cc:209-355 for
+// keyframe -> frame, :642-788 for keyframe -> keyframe).  valid1[idx1] folds "has a map point
+// that is not bad" (:248-251, :684-688); valid2[idx2] (NULL = all) folds the same test on the
+// second keyframe (:701-704); claimed second-side features are vpMapPointMatches / vbMatched2.
+// max_dist is inclusive: TH_LOW for :284, TH_LOW - 1 for :721.
+int oracle_search_by_bow(const oracle_frame* f1, const oracle_feature_vector* fv1, const uint8_t* valid1,
+                         const oracle_frame* f2, const oracle_feature_vector* fv2, const uint8_t* valid2, int max_dist,
+                         float mfNNratio, int mbCheckOrientation, int* match12, int* match21) {
+    for (int i = 0; i < f1->n; i++) match12[i] = -1;
+    for (int i = 0; i < f2->n; i++) match21[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int it1 = 0, it2 = 0;
+    while (it1 < fv1->n_nodes && it2 < fv2->n_nodes) {
+        if (fv1->node_ids[it1] == fv2->node_ids[it2]) {
+            for (int a = fv1->start[it1]; a < fv1->start[it1 + 1]; a++) {
+                const unsigned int idx1 = fv1->items[a];
+                if (!valid1[idx1]) continue;
+                const uint8_t* d1 = f1->desc + (size_t)idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int b = fv2->start[it2]; b < fv2->start[it2 + 1]; b++) {
+                    const unsigned int idx2 = fv2->items[b];
+                    if (match21[idx2] >= 0) continue;
+                    if (valid2 && !valid2[idx2]) continue;
+                    const int dist = descriptor_distance(d1, f2->desc + (size_t)idx2 * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 <= max_dist) {
+                    if (static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+                        match12[idx1] = bestIdx2;
+                        match21[bestIdx2] = idx1;
+                        if (mbCheckOrientation) rotHist[rot_bin(f1->kps[idx1].angle, f2->kps[bestIdx2].angle)].push_back(idx1);
+                        nmatches++;
+                    }
+                }
+            }
+            it1++;
+            it2++;
+        } else if (fv1->node_ids[it1] < fv2->node_ids[it2]) {
+            it1 = std::lower_bound(fv1->node_ids, fv1->node_ids + fv1->n_nodes, fv2->node_ids[it2]) - fv1->node_ids;
+        } else {
+            it2 = std::lower_bound(fv2->node_ids, fv2->node_ids + fv2->n_nodes, fv1->node_ids[it1]) - fv2->node_ids;
+        }
+    }
+    if (mbCheckOrientation) {
+        int sizes[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) {
+                match21[match12[idx1]] = -1;
+                match12[idx1] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:170-190 (CheckDistEpipolarLine)
+static bool check_dist_epipolar_line(const oracle_keypoint& kp1, const oracle_keypoint& kp2, const float* F12,
+                                     const float* sigma2) {
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2[kp2.octave];
+}
+
+// reference src/ORBmatcher.cc:803-992 from the point where the epipole (ex, ey) and F12 are
+// known (:809-818 is pose algebra).  has_mp*: the keypoint already holds a map point
+// (:858, :882); u_right*: mvuRight.  F12 row-major 3x3.  match12 = vMatches12.
+int oracle_search_for_triangulation(const oracle_frame* f1, const oracle_feature_vector* fv1, const uint8_t* has_mp1,
+                                    const float* u_right1, const oracle_frame* f2, const oracle_feature_vector* fv2,
+                                    const uint8_t* has_mp2, const float* u_right2, const float* F12, float ex, float ey,
+                                    const float* level_sigma2, int bOnlyStereo, int mbCheckOrientation, int* vMatches12) {
+    int nmatches = 0;
+    std::vector<bool> vbMatched2(f2->n, false);
+    for (int i = 0; i < f1->n; i++) vMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int it1 = 0, it2 = 0;
+    while (it1 < fv1->n_nodes && it2 < fv2->n_nodes) {
+        if (fv1->node_ids[it1] == fv2->node_ids[it2]) {
+            for (int a = fv1->start[it1]; a < fv1->start[it1 + 1]; a++) {
+                const size_t idx1 = fv1->items[a];
+                if (has_mp1[idx1]) continue;
+                const bool bStereo1 = u_right1[idx1] >= 0;
+                if (bOnlyStereo)
+                    if (!bStereo1) continue;
+                const oracle_keypoint& kp1 = f1->kps[idx1];
+                const uint8_t* d1 = f1->desc + idx1 * 32;
+                int bestDist = TH_LOW;
+                int bestIdx2 = -1;
+                for (int b = fv2->start[it2]; b < fv2->start[it2 + 1]; b++) {
+                    size_t idx2 = fv2->items[b];
+                    if (vbMatched2[idx2] || has_mp2[idx2]) continue;
+                    const bool bStereo2 = u_right2[idx2] >= 0;
+                    if (bOnlyStereo)
+                        if (!bStereo2) continue;
+                    const int dist = descriptor_distance(d1, f2->desc + idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const oracle_keypoint& kp2 = f2->kps[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - kp2.x;
+                        const float distey = ey - kp2.y;
+                        if (distex * distex + distey * distey < 100 * f2->scale_factors[kp2.octave]) continue;
+                    }
+                    if (check_dist_epipolar_line(kp1, kp2, F12, level_sigma2)) {
+                        bestIdx2 = idx2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    const oracle_keypoint& kp2 = f2->kps[bestIdx2];
+                    vMatches12[idx1] = bestIdx2;  // the reference never sets vbMatched2 here
+                    nmatches++;
+                    if (mbCheckOrientation) rotHist[rot_bin(kp1.angle, kp2.angle)].push_back((int)idx1);
+                }
+            }
+            it1++;
+            it2++;
+        } else if (fv1->node_ids[it1] < fv2->node_ids[it2]) {
+            it1 = std::lower_bound(fv1->node_ids, fv1->node_ids + fv1->n_nodes, fv2->node_ids[it2]) - fv1->node_ids;
+        } else {
+            it2 = std::lower_bound(fv2->node_ids, fv2->node_ids + fv2->n_nodes, fv1->node_ids[it1]) - fv2->node_ids;
+        }
+    }
+    if (mbCheckOrientation) {
+        int sizes[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) {
+                vMatches12[idx1] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+// The candidate loop shared by Fuse (reference src/ORBmatcher.cc:1066-1120), the Sim3 form of
+// Fuse (:1233-1262) and both directions of SearchBySim3 (:1391-1416, :1462-1489): query i is a
+// map point already projected to (u, v) with predicted level `level`; the closest descriptor
+// among the keypoints in the window whose octave is level-1 or level wins (first one on ties).
+// chi2_gate = 1 adds Fuse's reprojection test (:1085-1111): kf_u_right = mvuRight of the
+// keyframe, q_u_right = u - bf*invz of the query, inv_level_sigma2 = mvInvLevelSigma2.
+// best_dist is 256 when nothing qualified.
+void oracle_window_best(const oracle_frame* kf, int n, const uint8_t* valid, const float* u_, const float* v_,
+                        const float* radius_, const int* level, const uint8_t* desc, int chi2_gate,
+                        const float* kf_u_right, const float* q_u_right, const float* inv_level_sigma2, int* best_idx,
+                        int* best_dist) {
+    const oracle_frame& K = *kf;
+    Grid g = build_grid(K);
+    for (int i = 0; i < n; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+        if (!valid[i]) continue;
+        const float u = u_[i], v = v_[i];
+        const int nPredictedLevel = level[i];
+        const std::vector<int> vIndices = features_in_area(K, g, u, v, radius_[i]);
+        if (vIndices.empty()) continue;
+        const uint8_t* dMP = desc + (size_t)i * 32;
+        int bestDist = 256;
+        int bestIdx = -1;
+        for (int idx : vIndices) {
+            const oracle_keypoint& kp = K.kps[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (chi2_gate) {
+                if (kf_u_right[idx] >= 0) {
+                    const float ur = q_u_right[i];
+                    const float ex = u - kp.x;
+                    const float ey = v - kp.y;
+                    const float er = ur - kf_u_right[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u - kp.x;
+                    const float ey = v - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            const int dist = descriptor_distance(dMP, K.desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        best_idx[i] = bestIdx;
+        best_dist[i] = bestDist;
+    }
+}
+
+// reference src/ORBmatcher.cc:1298-1517 from the projections on: q12 are the map points of
+// keyframe 1 projected into keyframe 2 (one per keypoint of keyframe 1; valid folds :1355-1385),
+// q21 the reverse.  match12[i1] = keypoint of keyframe 2 when both directions agree (:1499-1514).
+int oracle_search_by_sim3(const oracle_frame* kf1, const oracle_frame* kf2, const uint8_t* valid12, const float* u12,
+                          const float* v12, const float* r12, const int* level12, const uint8_t* desc1,
+                          const uint8_t* valid21, const float* u21, const float* v21, const float* r21,
+                          const int* level21, const uint8_t* desc2, int* match12) {
+    std::vector<int> vnMatch1(kf1->n, -1), vnMatch2(kf2->n, -1), d1(kf1->n), d2(kf2->n);
+    oracle_window_best(kf2, kf1->n, valid12, u12, v12, r12, level12, desc1, 0, nullptr, nullptr, nullptr, vnMatch1.data(),
+                       d1.data());
+    oracle_window_best(kf1, kf2->n, valid21, u21, v21, r21, level21, desc2, 0, nullptr, nullptr, nullptr, vnMatch2.data(),
+                       d2.data());
+    for (int i = 0; i < kf1->n; i++)
+        if (d1[i] > TH_HIGH) vnMatch1[i] = -1;
+    for (int i = 0; i < kf2->n; i++)
+        if (d2[i] > TH_HIGH) vnMatch2[i] = -1;
+    int nFound = 0;
+    for (int i1 = 0; i1 < kf1->n; i1++) {
+        match12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) {
+                match12[i1] = idx2;
+                nFound++;
+            }
+        }
+    }
+    return nFound;
+}
+
 }  // extern "C"

@@ -137,6 +137,30 @@ int oracle_search_by_projection_keyframe(const oracle_frame* cur, int n, const u
 int oracle_search_by_projection_sim3(const oracle_frame* kf, int n, const uint8_t* valid, const float* u,
                                      const float* v, const int* level, const uint8_t* desc, int th, int* matched);
 
+/* DBoW2::FeatureVector as CSR: node ids ascending, items = keypoint indices in insertion order. */
+typedef struct oracle_feature_vector {
+    int n_nodes;
+    const uint32_t* node_ids;
+    const int* start; /* n_nodes + 1 */
+    const uint32_t* items;
+} oracle_feature_vector;
+
+int oracle_search_by_bow(const oracle_frame* f1, const oracle_feature_vector* fv1, const uint8_t* valid1,
+                         const oracle_frame* f2, const oracle_feature_vector* fv2, const uint8_t* valid2, int max_dist,
+                         float nn_ratio, int check_orientation, int* match12, int* match21);
+int oracle_search_for_triangulation(const oracle_frame* f1, const oracle_feature_vector* fv1, const uint8_t* has_mp1,
+                                    const float* u_right1, const oracle_frame* f2, const oracle_feature_vector* fv2,
+                                    const uint8_t* has_mp2, const float* u_right2, const float* F12, float ex, float ey,
+                                    const float* level_sigma2, int only_stereo, int check_orientation, int* match12);
+void oracle_window_best(const oracle_frame* kf, int n, const uint8_t* valid, const float* u, const float* v,
+                        const float* radius, const int* level, const uint8_t* desc, int chi2_gate,
+                        const float* kf_u_right, const float* q_u_right, const float* inv_level_sigma2, int* best_idx,
+                        int* best_dist);
+int oracle_search_by_sim3(const oracle_frame* kf1, const oracle_frame* kf2, const uint8_t* valid12, const float* u12,
+                          const float* v12, const float* r12, const int* level12, const uint8_t* desc1,
+                          const uint8_t* valid21, const float* u21, const float* v21, const float* r21,
+                          const int* level21, const uint8_t* desc2, int* match12);
+
 /* Brute-force 2-nearest search with the serial-scan semantics of the
  * reference's descriptor loops (src/ORBmatcher.cc:260-288): strict '<'
  * updates, second-best may equal best, ratio and TH_LOW tests. */

@@ -330,3 +330,79 @@ def knn2(q, t):
     bi, bd, sd = (np.zeros(nq, np.int32) for _ in range(3))
     lib().oracle_knn2(_p(q), nq, _p(t), len(t), _p(bi), _p(bd), _p(sd))
     return bi, bd, sd
+
+
+# ---------------------------------------------------------------- vocabulary-guided searches
+class FeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("node_ids", C.c_void_p), ("start", C.c_void_p), ("items", C.c_void_p)]
+
+
+def feature_vector(fv):
+    pairs = sorted(fv.items()) if isinstance(fv, dict) else list(fv)
+    ids = np.array([p[0] for p in pairs], np.uint32)
+    start = np.zeros(len(pairs) + 1, np.int32)
+    for i, p in enumerate(pairs):
+        start[i + 1] = start[i] + len(p[1])
+    items = np.ascontiguousarray(np.concatenate([np.asarray(p[1], np.uint32) for p in pairs]).astype(np.uint32)
+                                 if pairs and start[-1] > 0 else np.zeros(0, np.uint32))
+    return FeatVec(len(pairs), ids.ctypes.data, start.ctypes.data, items.ctypes.data), (ids, start, items)
+
+
+def search_by_bow(f1, fv1, valid1, f2, fv2, valid2, max_dist, nn_ratio, check_ori):
+    s1, k1 = feature_vector(fv1)
+    s2, k2 = feature_vector(fv2)
+    v1 = np.ascontiguousarray(valid1, np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    m12 = np.full(max(f1.n, 1), -1, np.int32)
+    m21 = np.full(max(f2.n, 1), -1, np.int32)
+    fn = lib().oracle_search_by_bow
+    fn.restype = C.c_int
+    n = fn(C.byref(f1.c), C.byref(s1), _p(v1), C.byref(f2.c), C.byref(s2), None if v2 is None else _p(v2),
+           C.c_int(max_dist), C.c_float(nn_ratio), C.c_int(int(check_ori)), _p(m12), _p(m21))
+    return n, m12[:f1.n], m21[:f2.n]
+
+
+def search_for_triangulation(f1, fv1, has_mp1, ur1, f2, fv2, has_mp2, ur2, F12, ex, ey, level_sigma2, only_stereo,
+                             check_ori):
+    s1, k1 = feature_vector(fv1)
+    s2, k2 = feature_vector(fv2)
+    a = [np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(ur1, np.float32),
+         np.ascontiguousarray(has_mp2, np.uint8), np.ascontiguousarray(ur2, np.float32),
+         np.ascontiguousarray(F12, np.float32).reshape(9), np.ascontiguousarray(level_sigma2, np.float32)]
+    m12 = np.full(max(f1.n, 1), -1, np.int32)
+    fn = lib().oracle_search_for_triangulation
+    fn.restype = C.c_int
+    n = fn(C.byref(f1.c), C.byref(s1), _p(a[0]), _p(a[1]), C.byref(f2.c), C.byref(s2), _p(a[2]), _p(a[3]), _p(a[4]),
+           C.c_float(ex), C.c_float(ey), _p(a[5]), C.c_int(int(only_stereo)), C.c_int(int(check_ori)), _p(m12))
+    return n, m12[:f1.n]
+
+
+def window_best(kf, valid, u, v, radius, level, desc, chi2_gate=False, kf_u_right=None, q_u_right=None,
+                inv_level_sigma2=None):
+    n = len(u)
+    a = [np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32),
+         np.ascontiguousarray(radius, np.float32), np.ascontiguousarray(level, np.int32),
+         np.ascontiguousarray(desc, np.uint8)]
+    kur = None if kf_u_right is None else np.ascontiguousarray(kf_u_right, np.float32)
+    qur = None if q_u_right is None else np.ascontiguousarray(q_u_right, np.float32)
+    isg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+    bi = np.full(max(n, 1), -1, np.int32)
+    bd = np.full(max(n, 1), 256, np.int32)
+    fn = lib().oracle_window_best
+    fn.restype = None
+    fn(C.byref(kf.c), C.c_int(n), *[_p(x) for x in a], C.c_int(int(chi2_gate)), None if kur is None else _p(kur),
+       None if qur is None else _p(qur), None if isg is None else _p(isg), _p(bi), _p(bd))
+    return bi[:n], bd[:n]
+
+
+def search_by_sim3(kf1, kf2, q12, q21):
+    def prep(q):
+        return [np.ascontiguousarray(q[0], np.uint8), np.ascontiguousarray(q[1], np.float32),
+                np.ascontiguousarray(q[2], np.float32), np.ascontiguousarray(q[3], np.float32),
+                np.ascontiguousarray(q[4], np.int32), np.ascontiguousarray(q[5], np.uint8)]
+    a, b = prep(q12), prep(q21)
+    m12 = np.full(max(kf1.n, 1), -1, np.int32)
+    fn = lib().oracle_search_by_sim3
+    fn.restype = C.c_int
+    n = fn(C.byref(kf1.c), C.byref(kf2.c), *[_p(x) for x in a], *[_p(x) for x in b], _p(m12))
+    return n, m12[:kf1.n]

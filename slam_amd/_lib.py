@@ -54,6 +54,11 @@ class Pyramid(C.Structure):
                 ("height", C.c_int32 * MAX_LEVELS), ("pitch", C.c_size_t * MAX_LEVELS)]
 
 
+class FeatureVector(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("n_items", C.c_int32), ("node_ids", C.c_void_p), ("start", C.c_void_p),
+                ("items", C.c_void_p)]
+
+
 # Every exported symbol of include/orbx.h: (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -100,6 +105,15 @@ SIGNATURES = {
     "orbm_search_by_projection": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp, _vp,
                                        C.POINTER(_i), _i]),
+    "orbm_search_by_bow": (_i, [_vp, C.POINTER(MFrame), C.POINTER(FeatureVector), _vp, C.POINTER(MFrame),
+                                C.POINTER(FeatureVector), _vp, _i, _f, _i, _vp, _vp, _vp, _i]),
+    "orbm_search_for_triangulation": (_i, [_vp, C.POINTER(MFrame), C.POINTER(FeatureVector), _vp, _vp, C.POINTER(MFrame),
+                                           C.POINTER(FeatureVector), _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _vp,
+                                           _vp, _i]),
+    "orbm_window_best": (_i, [_vp, C.POINTER(MFrame), _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp,
+                              _i]),
+    "orbm_search_by_sim3": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp, _vp, _vp, _i]),
     "orbm_compute_stereo_matches": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), C.POINTER(Pyramid),
                                          C.POINTER(Pyramid), _vp, _vp, _f, _f, _vp, _vp, _vp, _i]),
     "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),

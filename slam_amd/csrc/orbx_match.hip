@@ -629,6 +629,285 @@ __device__ __forceinline__ u32 umed3(u32 a, u32 b, u32 c) {
 #define KNN_QPT 4          // queries per thread
 #define KNN_IDX_BITS 22    // train rows per launch chunk: (distance << 22) | row fits 32 bits
 
+// ------------------------------------------------------------------ vocabulary-guided searches
+// DBoW2::FeatureVector as CSR (node ids ascending; items = keypoint indices in list order).
+struct DevFeatVec {
+    int nNodes;
+    const u32* nodeIds;
+    const int* start;
+    const u32* items;
+};
+
+// Index of `node` in v.nodeIds or -1 (the std::map lookups of reference
+// src/ORBmatcher.cc:234-327 reduce to an intersection of the two sorted id lists).
+__device__ __forceinline__ int find_node(const DevFeatVec& v, u32 node) {
+    int lo = 0, hi = v.nNodes - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const u32 id = v.nodeIds[mid];
+        if (id == node) return mid;
+        if (id < node) lo = mid + 1;
+        else hi = mid - 1;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (u32)__shfl_xor((int)v, o));
+    return v;
+}
+
+// ORBmatcher::SearchByBoW, both overloads (reference src/ORBmatcher.cc:209-355, :642-788):
+// one wave per vocabulary node present in both feature vectors.  Second-side keypoints
+// belong to one node only, so the claims of different nodes never meet; inside a node the
+// first-side keypoints are taken in list order and the second-side list is scanned by the
+// 64 lanes (best = smallest distance, first in list order; second best counts duplicates).
+__global__ __launch_bounds__(64) void k_bow_match(DevFrame f1, DevFeatVec v1, const u8* __restrict__ valid1, DevFrame f2,
+                                                   DevFeatVec v2, const u8* __restrict__ valid2, int maxDist, float nnRatio,
+                                                   int checkOri, int* match12, int* match21, int* bin12, int* hist) {
+    const int n1 = blockIdx.x, lane = threadIdx.x;
+    const int n2 = find_node(v2, v1.nodeIds[n1]);
+    if (n2 < 0) return;
+    const int b2 = v2.start[n2], e2 = v2.start[n2 + 1];
+    for (int a = v1.start[n1]; a < v1.start[n1 + 1]; a++) {
+        const int idx1 = (int)v1.items[a];
+        if (!valid1[idx1]) continue;
+        const uint4* d1 = (const uint4*)(f1.desc + (i64)idx1 * 32);
+        const uint4 a0 = d1[0], a1 = d1[1];
+        u64 bkey = ~0ull;
+        u32 second = 256;
+        for (int k = b2 + lane; k < e2; k += 64) {
+            const int idx2 = (int)v2.items[k];
+            if (match21[idx2] >= 0) continue;
+            if (valid2 && !valid2[idx2]) continue;
+            const uint4* d2 = (const uint4*)(f2.desc + (i64)idx2 * 32);
+            const u32 dist = (u32)hamming256(a0, a1, d2[0], d2[1]);
+            const u64 key = ((u64)dist << 32) | (u32)(k - b2);
+            if (key < bkey) {
+                if (bkey != ~0ull) second = min(second, (u32)(bkey >> 32));
+                bkey = key;
+            } else {
+                second = min(second, dist);
+            }
+        }
+        const u64 win = wave_min_u64(bkey);
+        const u32 mine = bkey == win ? second : (bkey == ~0ull ? 256u : (u32)(bkey >> 32));
+        const u32 bestDist2 = wave_min_u32(mine);
+        if (win == ~0ull) continue;
+        const int bestDist1 = (int)(win >> 32);
+        if (bestDist1 <= maxDist && (float)bestDist1 < __fmul_rn(nnRatio, (float)bestDist2)) {
+            const int bestIdx2 = (int)v2.items[b2 + (int)(u32)win];
+            if (lane == 0) {
+                match12[idx1] = bestIdx2;
+                match21[bestIdx2] = idx1;
+                if (checkOri) {
+                    const int bin = rot_bin(f1.kps[idx1].angle, f2.kps[bestIdx2].angle);
+                    bin12[idx1] = bin;
+                    atomicAdd(&hist[bin], 1);
+                }
+            }
+            __threadfence_block();
+        }
+    }
+}
+
+struct TriParams {
+    float F12[9];
+    float ex, ey;
+    float scale2[ORBM_MAX_LEVELS], sigma2[ORBM_MAX_LEVELS];
+    int onlyStereo, checkOri;
+};
+
+// ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:803-992), same node
+// pairing.  The reference never marks second-side keypoints as taken, so every first-side
+// keypoint is independent: among the second-side keypoints of the node that pass the
+// distance, epipole and epipolar-line gates the smallest distance wins, the LAST one in list
+// order on ties (:896 lets an equal distance replace the best).
+__global__ __launch_bounds__(64) void k_tri_match(DevFrame f1, DevFeatVec v1, const u8* __restrict__ hasMp1,
+                                                   const float* __restrict__ uRight1, DevFrame f2, DevFeatVec v2,
+                                                   const u8* __restrict__ hasMp2, const float* __restrict__ uRight2,
+                                                   TriParams P, int* match12, int* bin12, int* hist) {
+    const int n1 = blockIdx.x, lane = threadIdx.x;
+    const int n2 = find_node(v2, v1.nodeIds[n1]);
+    if (n2 < 0) return;
+    const int b2 = v2.start[n2], e2 = v2.start[n2 + 1];
+    for (int a = v1.start[n1]; a < v1.start[n1 + 1]; a++) {
+        const int idx1 = (int)v1.items[a];
+        if (hasMp1[idx1]) continue;
+        const bool bStereo1 = uRight1[idx1] >= 0;
+        if (P.onlyStereo && !bStereo1) continue;
+        const orbx_keypoint kp1 = f1.kps[idx1];
+        const uint4* d1 = (const uint4*)(f1.desc + (i64)idx1 * 32);
+        const uint4 a0 = d1[0], a1 = d1[1];
+        // epipolar line of kp1 in the second image (reference src/ORBmatcher.cc:178-180)
+        const float la = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, P.F12[0]), __fmul_rn(kp1.y, P.F12[3])), P.F12[6]);
+        const float lb = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, P.F12[1]), __fmul_rn(kp1.y, P.F12[4])), P.F12[7]);
+        const float lc = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, P.F12[2]), __fmul_rn(kp1.y, P.F12[5])), P.F12[8]);
+        const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+        u64 bkey = ~0ull;
+        for (int k = b2 + lane; k < e2; k += 64) {
+            const int idx2 = (int)v2.items[k];
+            if (hasMp2[idx2]) continue;
+            const bool bStereo2 = uRight2[idx2] >= 0;
+            if (P.onlyStereo && !bStereo2) continue;
+            const uint4* d2 = (const uint4*)(f2.desc + (i64)idx2 * 32);
+            const int dist = hamming256(a0, a1, d2[0], d2[1]);
+            if (dist > TH_LOW) continue;
+            const orbx_keypoint kp2 = f2.kps[idx2];
+            const int oct = min(max(kp2.octave, 0), ORBM_MAX_LEVELS - 1);
+            if (!bStereo1 && !bStereo2) {
+                const float distex = __fsub_rn(P.ex, kp2.x), distey = __fsub_rn(P.ey, kp2.y);
+                if (__fadd_rn(__fmul_rn(distex, distex), __fmul_rn(distey, distey)) < __fmul_rn(100.0f, P.scale2[oct])) continue;
+            }
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, kp2.x), __fmul_rn(lb, kp2.y)), lc);
+            if (den == 0) continue;
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < 3.84 * (double)P.sigma2[oct])) continue;
+            const u64 key = ((u64)(u32)dist << 32) | (0xFFFFFFFFu - (u32)(k - b2));
+            bkey = key < bkey ? key : bkey;
+        }
+        const u64 win = wave_min_u64(bkey);
+        if (win == ~0ull) continue;
+        const int bestIdx2 = (int)v2.items[b2 + (int)(0xFFFFFFFFu - (u32)win)];
+        if (lane == 0) {
+            match12[idx1] = bestIdx2;
+            if (P.checkOri) {
+                const int bin = rot_bin(kp1.angle, f2.kps[bestIdx2].angle);
+                bin12[idx1] = bin;
+                atomicAdd(&hist[bin], 1);
+            }
+        }
+    }
+}
+
+// Rotation-consistency cull shared by the two kernels above (reference
+// src/ORBmatcher.cc:330-352): keep the three fullest bins, count what is left.
+__global__ __launch_bounds__(256) void k_bow_finish(int n1, int checkOri, int* match12, int* match21, const int* bin12,
+                                                     const int* hist, int* nmatchesOut) {
+    __shared__ int keep[3];
+    __shared__ int total;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int i1 = -1, i2 = -1, i3 = -1;
+        if (checkOri) three_maxima(hist, HISTO_LENGTH, i1, i2, i3);
+        keep[0] = i1;
+        keep[1] = i2;
+        keep[2] = i3;
+        total = 0;
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < n1; i += 256) {
+        const int m = match12[i];
+        if (m < 0) continue;
+        if (checkOri) {
+            const int bin = bin12[i];
+            if (bin != keep[0] && bin != keep[1] && bin != keep[2]) {
+                if (match21) match21[m] = -1;
+                match12[i] = -1;
+                continue;
+            }
+        }
+        mine++;
+    }
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (tid == 0) *nmatchesOut = total;
+}
+
+struct WindowBestParams {
+    float invSigma2[ORBM_MAX_LEVELS];
+    int chi2Gate;
+};
+
+// The candidate loop of Fuse and SearchBySim3 (reference src/ORBmatcher.cc:1066-1120,
+// :1233-1262, :1391-1416, :1462-1489): queries are independent, one wave each.  The window is
+// walked in GetFeaturesInArea order; keypoints one level below or at the predicted level
+// qualify; with chi2Gate the reprojection test of Fuse (:1085-1111) is applied first.  The
+// closest descriptor wins, the first one met on ties; 256 / -1 when nothing qualified.
+__global__ __launch_bounds__(256) void k_window_best(DevFrame kf, const int* __restrict__ cellStart,
+                                                      const int* __restrict__ cellItems, int n, const u8* __restrict__ valid,
+                                                      const float* __restrict__ qu, const float* __restrict__ qv,
+                                                      const float* __restrict__ qr, const int* __restrict__ qlevel,
+                                                      const u8* __restrict__ qdesc, const float* __restrict__ kfURight,
+                                                      const float* __restrict__ qURight, WindowBestParams P, int* bestIdx,
+                                                      int* bestDist) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= n) return;
+    const int lane = threadIdx.x & 63;
+    int outIdx = -1, outDist = 256;
+    if (valid[q]) {
+        Query qq;
+        qq.x = qu[q];
+        qq.y = qv[q];
+        qq.r = qr[q];
+        const int level = qlevel[q];
+        qq.minLevel = level - 1;
+        qq.maxLevel = level;
+        qq.useRight = false;
+        qq.ur = qq.rGate = 0.f;
+        const uint4* dq = (const uint4*)(qdesc + (i64)q * 32);
+        const uint4 a0 = dq[0], a1 = dq[1];
+        const float ur = (P.chi2Gate && qURight) ? qURight[q] : 0.f;
+        u64 bkey = ~0ull;
+        walk_window(kf, cellStart, cellItems, nullptr, qq, [&](int pos, int idx) {
+            const orbx_keypoint kp = kf.kps[idx];
+            if (P.chi2Gate) {
+                const int oct = min(max(kp.octave, 0), ORBM_MAX_LEVELS - 1);
+                const float ex = __fsub_rn(qq.x, kp.x), ey = __fsub_rn(qq.y, kp.y);
+                const float kur = kfURight ? kfURight[idx] : -1.f;
+                if (kur >= 0) {
+                    const float er = __fsub_rn(ur, kur);
+                    const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                    if ((double)__fmul_rn(e2, P.invSigma2[oct]) > 7.8) return;
+                } else {
+                    const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                    if ((double)__fmul_rn(e2, P.invSigma2[oct]) > 5.99) return;
+                }
+            }
+            const uint4* dk = (const uint4*)(kf.desc + (i64)idx * 32);
+            const u32 dist = (u32)hamming256(a0, a1, dk[0], dk[1]);
+            // distance, then ordinal in walk order (first met wins ties), then the keypoint index
+            // itself (frames hold fewer than 2^20 keypoints)
+            const u64 key = ((u64)dist << 40) | ((u64)(u32)pos << 20) | (u32)idx;
+            bkey = key < bkey ? key : bkey;
+        });
+        const u64 win = wave_min_u64(bkey);
+        if (win != ~0ull) {
+            outDist = (int)(win >> 40);
+            outIdx = (int)(win & 0xFFFFFu);
+        }
+    }
+    if (lane == 0) {
+        bestIdx[q] = outIdx;
+        bestDist[q] = outDist;
+    }
+}
+
+// Agreement step of SearchBySim3 (reference src/ORBmatcher.cc:1499-1514).
+__global__ __launch_bounds__(256) void k_sim3_agree(int n1, int n2, const int* __restrict__ idx12, const int* __restrict__ d12,
+                                                     const int* __restrict__ idx21, const int* __restrict__ d21, int* match12,
+                                                     int* nFound) {
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i1 = threadIdx.x; i1 < n1; i1 += 256) {
+        int m = -1;
+        const int idx2 = d12[i1] <= TH_HIGH ? idx12[i1] : -1;
+        if (idx2 >= 0 && idx2 < n2) {
+            const int back = d21[idx2] <= TH_HIGH ? idx21[idx2] : -1;
+            if (back == i1) m = idx2;
+        }
+        match12[i1] = m;
+        mine += m >= 0;
+    }
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *nFound = total;
+}
+
 // ------------------------------------------------------------------ stereo
 // Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for a rectified
 // pair.  The reference's per-row candidate lists are replaced by a direct scan:
@@ -974,7 +1253,9 @@ enum {
     SL_QR, SL_QMIN, SL_QMAX, SL_QDESC, SL_COUNTS, SL_OFFS, SL_CAND_IDX, SL_CAND_DIST, SL_STATE_A, SL_STATE_B,
     SL_STATE_C, SL_STATE_D, SL_PREV, SL_SCALAR, SL_VALID, SL_U, SL_V, SL_INVZ, SL_HASOBS, SL_URIGHT, SL_SF,
     SL_KNN_Q, SL_KNN_T, SL_KNN_I, SL_KNN_D, SL_KNN_S, SL_KNN_I2, SL_KNN_D2, SL_KNN_S2, SL_ST_ROWS, SL_ST_SAD,
-    SL_ST_U, SL_ST_D
+    SL_ST_U, SL_ST_D, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, SL_BW_VALID1,
+    SL_BW_VALID2, SL_BW_M12, SL_BW_M21, SL_BW_BIN, SL_BW_HIST, SL_BW_UR1, SL_BW_UR2, SL_WB_LEVEL, SL_WB_IDX, SL_WB_DIST,
+    SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2
 };
 
 // Device view of a caller array: the pointer itself for device memory, else a staged copy.
@@ -1468,6 +1749,271 @@ int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const o
     if ((rc = copy_back(m, depth, (const float*)dD, (size_t)dl.n, mem_space))) return rc;
     if (n_stereo) ORBX_HIP_CHECK(hipMemcpyAsync(n_stereo, dKept, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     if (mem_space == ORBX_MEM_HOST || n_stereo) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+static int make_featvec(orbm_context* m, const orbm_feature_vector* fv, int slotNodes, int slotStart, int slotItems,
+                        int memSpace, DevFeatVec* out) {
+    if (!fv || fv->n_nodes < 0 || fv->n_items < 0 || (fv->n_nodes > 0 && (!fv->node_ids || !fv->start)) ||
+        (fv->n_items > 0 && !fv->items)) {
+        orbx_set_error("invalid feature vector");
+        return ORBX_ERR_INVALID;
+    }
+    int rc;
+    if ((rc = stage_in(m, slotNodes, fv->node_ids, (size_t)fv->n_nodes, memSpace, &out->nodeIds))) return rc;
+    if ((rc = stage_in(m, slotStart, (const int*)fv->start, (size_t)fv->n_nodes + 1, memSpace, &out->start))) return rc;
+    if ((rc = stage_in(m, slotItems, fv->items, (size_t)fv->n_items, memSpace, &out->items))) return rc;
+    out->nNodes = fv->n_nodes;
+    return ORBX_OK;
+}
+
+// host-side checks on a host-memory feature vector: ascending ids, monotone offsets, items in range
+static int check_featvec_host(const orbm_feature_vector* fv, int nKeypoints) {
+    for (int i = 0; i < fv->n_nodes; i++) {
+        if (i > 0 && fv->node_ids[i] <= fv->node_ids[i - 1]) {
+            orbx_set_error("feature vector: node ids must be strictly ascending");
+            return ORBX_ERR_INVALID;
+        }
+        if (fv->start[i] < 0 || fv->start[i + 1] < fv->start[i] || fv->start[i + 1] > fv->n_items) {
+            orbx_set_error("feature vector: bad offsets at node %d", i);
+            return ORBX_ERR_INVALID;
+        }
+    }
+    for (int i = 0; i < fv->n_items; i++)
+        if (fv->items[i] >= (uint32_t)nKeypoints) {
+            orbx_set_error("feature vector: item %d names keypoint %u of %d", i, fv->items[i], nKeypoints);
+            return ORBX_ERR_INVALID;
+        }
+    return ORBX_OK;
+}
+
+int orbm_search_by_bow(orbm_context* m, const orbm_frame* f1, const orbm_feature_vector* fv1, const uint8_t* valid1,
+                       const orbm_frame* f2, const orbm_feature_vector* fv2, const uint8_t* valid2, int max_dist,
+                       float nn_ratio, int check_orientation, int32_t* match12, int32_t* match21, int* nmatches,
+                       int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (!valid1 || !match12 || !match21 || !nmatches) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    DevFrame d1, d2;
+    if ((rc = make_frame(m, f1, SL_F1_KPS, SL_F1_DESC, mem_space, &d1))) return rc;
+    if ((rc = make_frame(m, f2, SL_F2_KPS, SL_F2_DESC, mem_space, &d2))) return rc;
+    if (mem_space == ORBX_MEM_HOST) {
+        if ((rc = check_featvec_host(fv1, d1.n)) || (rc = check_featvec_host(fv2, d2.n))) return rc;
+    }
+    DevFeatVec v1, v2;
+    if ((rc = make_featvec(m, fv1, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, mem_space, &v1))) return rc;
+    if ((rc = make_featvec(m, fv2, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, mem_space, &v2))) return rc;
+    const u8 *dValid1, *dValid2;
+    if ((rc = stage_in(m, SL_BW_VALID1, valid1, (size_t)d1.n, mem_space, &dValid1))) return rc;
+    if ((rc = stage_in(m, SL_BW_VALID2, valid2, (size_t)d2.n, mem_space, &dValid2))) return rc;
+    int *dM12, *dM21;
+    void *dBin, *dHist;
+    if ((rc = stage_out(m, SL_BW_M12, (int*)match12, (size_t)d1.n, mem_space, &dM12))) return rc;
+    if ((rc = stage_out(m, SL_BW_M21, (int*)match21, (size_t)d2.n, mem_space, &dM21))) return rc;
+    if ((rc = pool_get(m, SL_BW_BIN, (size_t)std::max(d1.n, 1) * sizeof(int), &dBin))) return rc;
+    if ((rc = pool_get(m, SL_BW_HIST, (HISTO_LENGTH + 2) * sizeof(int), &dHist))) return rc;
+    if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dM12, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
+    if (d2.n) ORBX_HIP_CHECK(hipMemsetAsync(dM21, 0xFF, (size_t)d2.n * sizeof(int), m->stream));
+    if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dBin, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
+    ORBX_HIP_CHECK(hipMemsetAsync(dHist, 0, (HISTO_LENGTH + 2) * sizeof(int), m->stream));
+    if (v1.nNodes > 0 && v2.nNodes > 0 && d1.n > 0 && d2.n > 0) {
+        hipLaunchKernelGGL(k_bow_match, dim3(v1.nNodes), dim3(64), 0, m->stream, d1, v1, dValid1, d2, v2, dValid2, max_dist,
+                           nn_ratio, check_orientation, dM12, dM21, (int*)dBin, (int*)dHist);
+        ORBX_HIP_CHECK(hipGetLastError());
+    }
+    int* dCount = (int*)dHist + HISTO_LENGTH;
+    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, m->stream, d1.n, check_orientation, dM12, dM21, (const int*)dBin,
+                       (const int*)dHist, dCount);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
+    if ((rc = copy_back(m, (int*)match21, (const int*)dM21, (size_t)d2.n, mem_space))) return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, dCount, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_search_for_triangulation(orbm_context* m, const orbm_frame* f1, const orbm_feature_vector* fv1,
+                                  const uint8_t* has_mp1, const float* u_right1, const orbm_frame* f2,
+                                  const orbm_feature_vector* fv2, const uint8_t* has_mp2, const float* u_right2,
+                                  const float* f12, float ex, float ey, const float* scale_factors2,
+                                  const float* level_sigma2_2, int nlevels, int only_stereo, int check_orientation,
+                                  int32_t* match12, int* nmatches, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (!has_mp1 || !has_mp2 || !u_right1 || !u_right2 || !f12 || !scale_factors2 || !level_sigma2_2 || !match12 ||
+        !nmatches || nlevels < 1 || nlevels > ORBM_MAX_LEVELS) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    DevFrame d1, d2;
+    if ((rc = make_frame(m, f1, SL_F1_KPS, SL_F1_DESC, mem_space, &d1))) return rc;
+    if ((rc = make_frame(m, f2, SL_F2_KPS, SL_F2_DESC, mem_space, &d2))) return rc;
+    if (mem_space == ORBX_MEM_HOST) {
+        if ((rc = check_featvec_host(fv1, d1.n)) || (rc = check_featvec_host(fv2, d2.n))) return rc;
+    }
+    DevFeatVec v1, v2;
+    if ((rc = make_featvec(m, fv1, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, mem_space, &v1))) return rc;
+    if ((rc = make_featvec(m, fv2, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, mem_space, &v2))) return rc;
+    const u8 *dMp1, *dMp2;
+    const float *dUr1, *dUr2;
+    if ((rc = stage_in(m, SL_BW_VALID1, has_mp1, (size_t)d1.n, mem_space, &dMp1))) return rc;
+    if ((rc = stage_in(m, SL_BW_VALID2, has_mp2, (size_t)d2.n, mem_space, &dMp2))) return rc;
+    if ((rc = stage_in(m, SL_BW_UR1, u_right1, (size_t)d1.n, mem_space, &dUr1))) return rc;
+    if ((rc = stage_in(m, SL_BW_UR2, u_right2, (size_t)d2.n, mem_space, &dUr2))) return rc;
+    TriParams P;
+    memset(&P, 0, sizeof(P));
+    for (int i = 0; i < 9; i++) P.F12[i] = f12[i];
+    P.ex = ex;
+    P.ey = ey;
+    for (int l = 0; l < nlevels; l++) {
+        P.scale2[l] = scale_factors2[l];
+        P.sigma2[l] = level_sigma2_2[l];
+    }
+    P.onlyStereo = only_stereo;
+    P.checkOri = check_orientation;
+    int* dM12;
+    void *dBin, *dHist;
+    if ((rc = stage_out(m, SL_BW_M12, (int*)match12, (size_t)d1.n, mem_space, &dM12))) return rc;
+    if ((rc = pool_get(m, SL_BW_BIN, (size_t)std::max(d1.n, 1) * sizeof(int), &dBin))) return rc;
+    if ((rc = pool_get(m, SL_BW_HIST, (HISTO_LENGTH + 2) * sizeof(int), &dHist))) return rc;
+    if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dM12, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
+    if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dBin, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
+    ORBX_HIP_CHECK(hipMemsetAsync(dHist, 0, (HISTO_LENGTH + 2) * sizeof(int), m->stream));
+    if (v1.nNodes > 0 && v2.nNodes > 0 && d1.n > 0 && d2.n > 0) {
+        hipLaunchKernelGGL(k_tri_match, dim3(v1.nNodes), dim3(64), 0, m->stream, d1, v1, dMp1, dUr1, d2, v2, dMp2, dUr2, P,
+                           dM12, (int*)dBin, (int*)dHist);
+        ORBX_HIP_CHECK(hipGetLastError());
+    }
+    int* dCount = (int*)dHist + HISTO_LENGTH;
+    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, m->stream, d1.n, check_orientation, dM12, (int*)nullptr,
+                       (const int*)dBin, (const int*)dHist, dCount);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, dCount, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+// Enqueues one window-best search; outputs stay on the device.
+static int run_window_best(orbm_context* m, const DevFrame& kf, int n, const u8* dValid, const float* dU, const float* dV,
+                           const float* dR, const int* dLevel, const u8* dDesc, int chi2Gate, const float* dKfUr,
+                           const float* dQUr, const float* invSigma2, int nlevels, int* dIdx, int* dDist) {
+    if (n == 0) return ORBX_OK;
+    int *cs, *ci;
+    int rc = build_grid(m, kf, &cs, &ci);
+    if (rc) return rc;
+    WindowBestParams P;
+    memset(&P, 0, sizeof(P));
+    P.chi2Gate = chi2Gate;
+    if (chi2Gate)
+        for (int l = 0; l < nlevels; l++) P.invSigma2[l] = invSigma2[l];
+    hipLaunchKernelGGL(k_window_best, dim3((n + 3) / 4), dim3(256), 0, m->stream, kf, (const int*)cs, (const int*)ci, n, dValid,
+                       dU, dV, dR, dLevel, dDesc, dKfUr, dQUr, P, dIdx, dDist);
+    ORBX_HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbm_window_best(orbm_context* m, const orbm_frame* kf, int n, const uint8_t* valid, const float* u, const float* v,
+                     const float* radius, const int32_t* level, const uint8_t* desc, int chi2_gate,
+                     const float* kf_u_right, const float* q_u_right, const float* inv_level_sigma2, int nlevels,
+                     int32_t* best_idx, int32_t* best_dist, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (n < 0 || !valid || !u || !v || !radius || !level || !desc || !best_idx || !best_dist ||
+        (chi2_gate && (!inv_level_sigma2 || nlevels < 1 || nlevels > ORBM_MAX_LEVELS))) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (n == 0) return ORBX_OK;
+    DevFrame dk;
+    if ((rc = make_frame(m, kf, SL_F2_KPS, SL_F2_DESC, mem_space, &dk))) return rc;
+    const u8 *dValid, *dDesc;
+    const float *dU, *dV, *dR, *dKfUr, *dQUr;
+    const int* dLevel;
+    if ((rc = stage_in(m, SL_VALID, valid, (size_t)n, mem_space, &dValid))) return rc;
+    if ((rc = stage_in(m, SL_U, u, (size_t)n, mem_space, &dU))) return rc;
+    if ((rc = stage_in(m, SL_V, v, (size_t)n, mem_space, &dV))) return rc;
+    if ((rc = stage_in(m, SL_QR, radius, (size_t)n, mem_space, &dR))) return rc;
+    if ((rc = stage_in(m, SL_WB_LEVEL, (const int*)level, (size_t)n, mem_space, &dLevel))) return rc;
+    if ((rc = stage_in(m, SL_QDESC, desc, (size_t)n * 32, mem_space, &dDesc))) return rc;
+    if ((rc = stage_in(m, SL_URIGHT, kf_u_right, (size_t)dk.n, mem_space, &dKfUr))) return rc;
+    if ((rc = stage_in(m, SL_WB_QUR, q_u_right, (size_t)n, mem_space, &dQUr))) return rc;
+    int *dIdx, *dDist;
+    if ((rc = stage_out(m, SL_WB_IDX, (int*)best_idx, (size_t)n, mem_space, &dIdx))) return rc;
+    if ((rc = stage_out(m, SL_WB_DIST, (int*)best_dist, (size_t)n, mem_space, &dDist))) return rc;
+    if ((rc = run_window_best(m, dk, n, dValid, dU, dV, dR, dLevel, dDesc, chi2_gate, dKfUr, dQUr, inv_level_sigma2, nlevels,
+                              dIdx, dDist)))
+        return rc;
+    if ((rc = copy_back(m, (int*)best_idx, (const int*)dIdx, (size_t)n, mem_space))) return rc;
+    if ((rc = copy_back(m, (int*)best_dist, (const int*)dDist, (size_t)n, mem_space))) return rc;
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_search_by_sim3(orbm_context* m, const orbm_frame* kf1, const orbm_frame* kf2, const uint8_t* valid12,
+                        const float* u12, const float* v12, const float* r12, const int32_t* level12,
+                        const uint8_t* mp_desc1, const uint8_t* valid21, const float* u21, const float* v21,
+                        const float* r21, const int32_t* level21, const uint8_t* mp_desc2, int32_t* match12, int* nfound,
+                        int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (!valid12 || !u12 || !v12 || !r12 || !level12 || !mp_desc1 || !valid21 || !u21 || !v21 || !r21 || !level21 ||
+        !mp_desc2 || !match12 || !nfound) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    DevFrame d1, d2;
+    if ((rc = make_frame(m, kf1, SL_F1_KPS, SL_F1_DESC, mem_space, &d1))) return rc;
+    if ((rc = make_frame(m, kf2, SL_F2_KPS, SL_F2_DESC, mem_space, &d2))) return rc;
+    *nfound = 0;
+    if (d1.n == 0) return ORBX_OK;
+    void *i12, *dd12, *i21, *dd21, *dCount;
+    if ((rc = pool_get(m, SL_WB_IDX, (size_t)d1.n * sizeof(int), &i12))) return rc;
+    if ((rc = pool_get(m, SL_WB_DIST, (size_t)d1.n * sizeof(int), &dd12))) return rc;
+    if ((rc = pool_get(m, SL_WB_IDX2, (size_t)std::max(d2.n, 1) * sizeof(int), &i21))) return rc;
+    if ((rc = pool_get(m, SL_WB_DIST2, (size_t)std::max(d2.n, 1) * sizeof(int), &dd21))) return rc;
+    if ((rc = pool_get(m, SL_SCALAR, 64, &dCount))) return rc;
+    // direction 1 -> 2: the map points of keyframe 1 searched among the keypoints of keyframe 2
+    {
+        const u8 *dValid, *dDesc;
+        const float *dU, *dV, *dR;
+        const int* dLevel;
+        if ((rc = stage_in(m, SL_VALID, valid12, (size_t)d1.n, mem_space, &dValid))) return rc;
+        if ((rc = stage_in(m, SL_U, u12, (size_t)d1.n, mem_space, &dU))) return rc;
+        if ((rc = stage_in(m, SL_V, v12, (size_t)d1.n, mem_space, &dV))) return rc;
+        if ((rc = stage_in(m, SL_QR, r12, (size_t)d1.n, mem_space, &dR))) return rc;
+        if ((rc = stage_in(m, SL_WB_LEVEL, (const int*)level12, (size_t)d1.n, mem_space, &dLevel))) return rc;
+        if ((rc = stage_in(m, SL_QDESC, mp_desc1, (size_t)d1.n * 32, mem_space, &dDesc))) return rc;
+        if ((rc = run_window_best(m, d2, d1.n, dValid, dU, dV, dR, dLevel, dDesc, 0, nullptr, nullptr, nullptr, 0, (int*)i12,
+                                  (int*)dd12)))
+            return rc;
+    }
+    // direction 2 -> 1 (the staging blocks are reused: stream order keeps the first search ahead of the copies)
+    if (d2.n > 0) {
+        const u8 *dValid, *dDesc;
+        const float *dU, *dV, *dR;
+        const int* dLevel;
+        if ((rc = stage_in(m, SL_BW_VALID2, valid21, (size_t)d2.n, mem_space, &dValid))) return rc;
+        if ((rc = stage_in(m, SL_BW_UR1, u21, (size_t)d2.n, mem_space, &dU))) return rc;
+        if ((rc = stage_in(m, SL_BW_UR2, v21, (size_t)d2.n, mem_space, &dV))) return rc;
+        if ((rc = stage_in(m, SL_WB_QUR, r21, (size_t)d2.n, mem_space, &dR))) return rc;
+        if ((rc = stage_in(m, SL_BW_BIN, (const int*)level21, (size_t)d2.n, mem_space, &dLevel))) return rc;
+        if ((rc = stage_in(m, SL_KNN_Q, mp_desc2, (size_t)d2.n * 32, mem_space, &dDesc))) return rc;
+        if ((rc = run_window_best(m, d1, d2.n, dValid, dU, dV, dR, dLevel, dDesc, 0, nullptr, nullptr, nullptr, 0, (int*)i21,
+                                  (int*)dd21)))
+            return rc;
+    }
+    int* dM12;
+    if ((rc = stage_out(m, SL_BW_M12, (int*)match12, (size_t)d1.n, mem_space, &dM12))) return rc;
+    hipLaunchKernelGGL(k_sim3_agree, dim3(1), dim3(256), 0, m->stream, d1.n, d2.n, (const int*)i12, (const int*)dd12,
+                       (const int*)i21, (const int*)dd21, dM12, (int*)dCount);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(nfound, dCount, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }
 

@@ -222,6 +222,100 @@ class ORBmatcher:
         return self.search_projected(KF, (np.asarray(valid, bool) & inimg).astype(np.uint8), u, v, radius,
                                      level - 1, level, desc, pol, claimed=matched)
 
+    # ---- vocabulary-guided searches
+    @staticmethod
+    def feature_vector(fv):
+        """DBoW2::FeatureVector given as {node id: [keypoint indices]} (or an ordered list of
+        (node id, indices) pairs) -> (ctypes struct, arrays that must stay alive)."""
+        pairs = sorted(fv.items()) if isinstance(fv, dict) else list(fv)
+        ids = np.array([p[0] for p in pairs], np.uint32)
+        start = np.zeros(len(pairs) + 1, np.int32)
+        for i, p in enumerate(pairs):
+            start[i + 1] = start[i] + len(p[1])
+        items = (np.concatenate([np.asarray(p[1], np.uint32) for p in pairs]) if pairs and start[-1] > 0
+                 else np.zeros(0, np.uint32)).astype(np.uint32)
+        items = np.ascontiguousarray(items)
+        s = _lib.FeatureVector(len(pairs), int(start[-1]), ids.ctypes.data, start.ctypes.data, items.ctypes.data)
+        return s, (ids, start, items)
+
+    def SearchByBoW(self, F1, fv1, valid1, F2, fv2, valid2=None, keyframe_pair=False):
+        """ORBmatcher::SearchByBoW.  keyframe_pair=False: (KeyFrame*, Frame&) overload (reference
+        src/ORBmatcher.cc:209-355), accepts distances <= TH_LOW; True: (KeyFrame*, KeyFrame*)
+        (:642-788), accepts < TH_LOW and needs valid2.  Returns (nmatches, match12, match21)."""
+        s1, k1 = self.feature_vector(fv1)
+        s2, k2 = self.feature_vector(fv2)
+        v1 = np.ascontiguousarray(valid1, np.uint8)
+        v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+        m12 = np.full(max(len(F1.kps), 1), -1, np.int32)
+        m21 = np.full(max(len(F2.kps), 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._lib.orbm_search_by_bow(self._m, C.byref(F1.c), C.byref(s1), v1.ctypes.data, C.byref(F2.c), C.byref(s2),
+                                           None if v2 is None else v2.ctypes.data,
+                                           self.TH_LOW - 1 if keyframe_pair else self.TH_LOW, self.mfNNratio,
+                                           int(self.mbCheckOrientation), m12.ctypes.data, m21.ctypes.data, C.addressof(n),
+                                           MEM_HOST))
+        return n.value, m12[:len(F1.kps)], m21[:len(F2.kps)]
+
+    def SearchForTriangulation(self, F1, fv1, has_mp1, u_right1, F2, fv2, has_mp2, u_right2, F12, ex, ey,
+                               level_sigma2_2, only_stereo=False):
+        """ORBmatcher::SearchForTriangulation (reference src/ORBmatcher.cc:803-992) with the epipole
+        (ex, ey) and F12 (3x3) computed by the caller.  Returns (nmatches, vMatches12)."""
+        s1, k1 = self.feature_vector(fv1)
+        s2, k2 = self.feature_vector(fv2)
+        h1 = np.ascontiguousarray(has_mp1, np.uint8)
+        h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        r1 = np.ascontiguousarray(u_right1, np.float32)
+        r2 = np.ascontiguousarray(u_right2, np.float32)
+        f12 = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sf2 = np.ascontiguousarray(F2.scale_factors, np.float32)
+        sg2 = np.ascontiguousarray(level_sigma2_2, np.float32)
+        m12 = np.full(max(len(F1.kps), 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._lib.orbm_search_for_triangulation(self._m, C.byref(F1.c), C.byref(s1), h1.ctypes.data, r1.ctypes.data,
+                                                      C.byref(F2.c), C.byref(s2), h2.ctypes.data, r2.ctypes.data,
+                                                      f12.ctypes.data, float(ex), float(ey), sf2.ctypes.data,
+                                                      sg2.ctypes.data, len(sf2), int(only_stereo),
+                                                      int(self.mbCheckOrientation), m12.ctypes.data, C.addressof(n),
+                                                      MEM_HOST))
+        return n.value, m12[:len(F1.kps)]
+
+    def window_best(self, KF, valid, u, v, radius, level, desc, chi2_gate=False, kf_u_right=None, q_u_right=None,
+                    inv_level_sigma2=None):
+        """Candidate loop of Fuse / SearchBySim3 (reference src/ORBmatcher.cc:1066-1120, :1391-1416):
+        per projected map point the closest keypoint of level-1..level in the window.
+        Returns (best_idx, best_dist)."""
+        n = len(u)
+        a = [np.ascontiguousarray(valid, np.uint8), np.ascontiguousarray(u, np.float32),
+             np.ascontiguousarray(v, np.float32), np.ascontiguousarray(radius, np.float32),
+             np.ascontiguousarray(level, np.int32), np.ascontiguousarray(desc, np.uint8)]
+        kur = None if kf_u_right is None else np.ascontiguousarray(kf_u_right, np.float32)
+        qur = None if q_u_right is None else np.ascontiguousarray(q_u_right, np.float32)
+        isg = None if inv_level_sigma2 is None else np.ascontiguousarray(inv_level_sigma2, np.float32)
+        bi = np.full(max(n, 1), -1, np.int32)
+        bd = np.full(max(n, 1), 256, np.int32)
+        check(self._lib.orbm_window_best(self._m, C.byref(KF.c), n, *[x.ctypes.data for x in a], int(chi2_gate),
+                                         None if kur is None else kur.ctypes.data,
+                                         None if qur is None else qur.ctypes.data,
+                                         None if isg is None else isg.ctypes.data, 0 if isg is None else len(isg),
+                                         bi.ctypes.data, bd.ctypes.data, MEM_HOST))
+        return bi[:n], bd[:n]
+
+    def SearchBySim3(self, KF1, KF2, q12, q21):
+        """ORBmatcher::SearchBySim3 (reference src/ORBmatcher.cc:1298-1517) from the projections on.
+        q12 = (valid, u, v, radius, level, desc) per keypoint of KF1 (its map point projected into
+        KF2), q21 the reverse.  Returns (nfound, match12)."""
+        def prep(q):
+            return [np.ascontiguousarray(q[0], np.uint8), np.ascontiguousarray(q[1], np.float32),
+                    np.ascontiguousarray(q[2], np.float32), np.ascontiguousarray(q[3], np.float32),
+                    np.ascontiguousarray(q[4], np.int32), np.ascontiguousarray(q[5], np.uint8)]
+        a, b = prep(q12), prep(q21)
+        assert len(a[1]) == len(KF1.kps) and len(b[1]) == len(KF2.kps)
+        m12 = np.full(max(len(KF1.kps), 1), -1, np.int32)
+        n = C.c_int(0)
+        check(self._lib.orbm_search_by_sim3(self._m, C.byref(KF1.c), C.byref(KF2.c), *[x.ctypes.data for x in a],
+                                            *[x.ctypes.data for x in b], m12.ctypes.data, C.addressof(n), MEM_HOST))
+        return n.value, m12[:len(KF1.kps)]
+
     # ---- stereo
     @staticmethod
     def pyramid_of(extractor, frame=0):

@@ -1,0 +1,182 @@
+"""Parity of the vocabulary-guided searches (SearchByBoW x2, SearchForTriangulation), the
+Fuse / SearchBySim3 candidate loop and SearchBySim3 against the CPU oracle, through the C ABI.
+
+Bar: bit-exact match arrays and counts.  The reference holds no fixtures for these functions
+("parity unpinned" beyond the oracle's own known-answer checks in tests/test_oracle_kat.py).
+Feature vectors are synthetic: keypoints of both views are bucketed by a hash of their
+position in the shared scene, so corresponding keypoints mostly share a node, as they do with a
+vocabulary tree.
+"""
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+BOUNDS = (0.0, 0.0, 640.0, 480.0)
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    from slam_amd.matcher import ORBmatcher
+    m = ORBmatcher(0.75, True)
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def pair(oracle):
+    p = oracle.params()
+    t = oracle.tables(p)
+    scene = synth.synth_image(700, 520, 91)
+    a = np.ascontiguousarray(scene[20:500, 30:670])
+    b = np.ascontiguousarray(scene[24:504, 18:658])  # view b sees scene shifted by (+12, -4)
+    ka, da = oracle.extract(p, a)
+    kb, db = oracle.extract(p, b)
+    return dict(sf=t["scale"], ka=ka, da=da, kb=kb, db=db, shift=(12.0, -4.0))
+
+
+def node_of(kps, dx, dy, nodes, jitter_seed):
+    """Vocabulary node of each keypoint: a hash of its 24-px scene block (views agree up to
+    block borders), with a few keypoints sent to a random node."""
+    bx = np.floor((kps["x"] + dx) / 24.0).astype(np.int64)
+    by = np.floor((kps["y"] + dy) / 24.0).astype(np.int64)
+    node = (bx * 7919 + by * 104729) % nodes
+    r = np.random.default_rng(jitter_seed)
+    flip = r.uniform(size=len(kps)) < 0.05
+    node[flip] = r.integers(0, nodes, flip.sum())
+    return node
+
+
+def feature_vector(node, order_seed):
+    """{node: [indices]}; list order is the insertion order of the reference (ascending keypoint
+    index), perturbed for a tenth of the nodes to make order matter."""
+    fv = {}
+    for i, n in enumerate(node):
+        fv.setdefault(int(n) * 3 + 5, []).append(i)
+    r = np.random.default_rng(order_seed)
+    for k in list(fv):
+        if r.uniform() < 0.1:
+            fv[k] = list(r.permutation(fv[k]))
+    return fv
+
+
+def frames(pair, oracle):
+    from slam_amd.matcher import FrameView
+    ga = FrameView(pair["ka"], pair["da"], BOUNDS, pair["sf"])
+    gb = FrameView(pair["kb"], pair["db"], BOUNDS, pair["sf"])
+    oa = oracle.FrameData(pair["ka"], pair["da"], BOUNDS, pair["sf"])
+    ob = oracle.FrameData(pair["kb"], pair["db"], BOUNDS, pair["sf"])
+    return ga, gb, oa, ob
+
+
+@pytest.mark.parametrize("nodes,kfpair,ori,ratio", [(97, False, True, 0.75), (97, True, True, 0.75), (13, False, True, 0.9),
+                                                    (1, True, False, 0.6), (400, False, False, 0.75)])
+def test_search_by_bow(oracle, pair, nodes, kfpair, ori, ratio):
+    from slam_amd.matcher import ORBmatcher
+    ga, gb, oa, ob = frames(pair, oracle)
+    sx, sy = pair["shift"]
+    fva = feature_vector(node_of(pair["ka"], 0, 0, nodes, 1), 3)
+    fvb = feature_vector(node_of(pair["kb"], -sx, -sy, nodes, 2), 4)
+    r = np.random.default_rng(nodes)
+    valid1 = (r.uniform(size=len(pair["ka"])) < 0.8).astype(np.uint8)
+    valid2 = (r.uniform(size=len(pair["kb"])) < 0.7).astype(np.uint8) if kfpair else None
+    m = ORBmatcher(ratio, ori)
+    try:
+        n, m12, m21 = m.SearchByBoW(ga, fva, valid1, gb, fvb, valid2, keyframe_pair=kfpair)
+    finally:
+        m.close()
+    on, o12, o21 = oracle.search_by_bow(oa, fva, valid1, ob, fvb, valid2, 49 if kfpair else 50, ratio, ori)
+    assert n == on and np.array_equal(m12, o12) and np.array_equal(m21, o21)
+    if nodes > 1:
+        assert n > 50
+    # what was matched is consistent: match21 inverts match12
+    idx = np.nonzero(m12 >= 0)[0]
+    assert np.array_equal(m21[m12[idx]], idx)
+
+
+def test_search_by_bow_disjoint_and_empty(oracle, pair, matcher):
+    ga, gb, oa, ob = frames(pair, oracle)
+    fva = {2: [0, 1, 2], 8: [3, 4]}
+    fvb = {3: [0, 1], 9: [2]}
+    v = np.ones(len(pair["ka"]), np.uint8)
+    n, m12, m21 = matcher.SearchByBoW(ga, fva, v, gb, fvb)
+    assert n == 0 and np.all(m12 == -1) and np.all(m21 == -1)
+    n, m12, m21 = matcher.SearchByBoW(ga, {}, v, gb, fvb)
+    assert n == 0
+    from slam_amd._lib import OrbxError
+    with pytest.raises(OrbxError):
+        matcher.SearchByBoW(ga, {1: [len(pair["ka"]) + 5]}, v, gb, fvb)   # item outside the frame
+
+
+@pytest.mark.parametrize("only_stereo,ori", [(False, True), (True, True), (False, False)])
+def test_search_for_triangulation(oracle, pair, only_stereo, ori):
+    from slam_amd.matcher import ORBmatcher
+    ga, gb, oa, ob = frames(pair, oracle)
+    sx, sy = pair["shift"]
+    fva = feature_vector(node_of(pair["ka"], 0, 0, 61, 1), 3)
+    fvb = feature_vector(node_of(pair["kb"], -sx, -sy, 61, 2), 4)
+    r = np.random.default_rng(5)
+    has1 = (r.uniform(size=len(pair["ka"])) < 0.3).astype(np.uint8)
+    has2 = (r.uniform(size=len(pair["kb"])) < 0.3).astype(np.uint8)
+    ur1 = np.where(r.uniform(size=len(pair["ka"])) < 0.5, pair["ka"]["x"] - 10, -1).astype(np.float32)
+    ur2 = np.where(r.uniform(size=len(pair["kb"])) < 0.5, pair["kb"]["x"] - 10, -1).astype(np.float32)
+    # pure image-plane translation (+12, -4) between the views: x2 = x1 + t, so the epipolar line of
+    # p1 passes through p1 + t with direction t; F = [t]x acting on homogeneous pixels
+    tx, ty = sx, sy
+    F = np.array([[0, 0, ty], [0, 0, -tx], [-ty, tx, 0]], np.float32)   # l2 = F^T-form used by the reference: a = x*F00+y*F10+F20
+    F12 = F.T.copy()
+    sigma2 = (pair["sf"] ** 2).astype(np.float32)
+    ex, ey = 320.0 + 4000.0, 240.0 - 1333.0
+    m = ORBmatcher(0.6, ori)
+    try:
+        n, m12 = m.SearchForTriangulation(ga, fva, has1, ur1, gb, fvb, has2, ur2, F12, ex, ey, sigma2, only_stereo)
+    finally:
+        m.close()
+    on, o12 = oracle.search_for_triangulation(oa, fva, has1, ur1, ob, fvb, has2, ur2, F12, ex, ey, sigma2, only_stereo, ori)
+    assert n == on and np.array_equal(m12, o12)
+    assert n > 20
+
+
+def projected_queries(src, dst_shift, sf, seed, frac_valid=0.85):
+    """Map points of the keypoints of one view projected into the other: position + noise,
+    predicted level = the keypoint's octave or one above."""
+    r = np.random.default_rng(seed)
+    n = len(src)
+    u = (src["x"] + dst_shift[0] + r.normal(0, 1.5, n)).astype(np.float32)
+    v = (src["y"] + dst_shift[1] + r.normal(0, 1.5, n)).astype(np.float32)
+    level = np.clip(src["octave"] + r.integers(0, 2, n), 0, 7).astype(np.int32)
+    valid = ((r.uniform(size=n) < frac_valid) & (u >= 0) & (u < 640) & (v >= 0) & (v < 480)).astype(np.uint8)
+    return valid, u, v, level
+
+
+@pytest.mark.parametrize("th,chi2", [(3.0, False), (7.5, False), (3.0, True), (10.0, True)])
+def test_window_best(oracle, pair, matcher, th, chi2):
+    ga, gb, oa, ob = frames(pair, oracle)
+    sx, sy = pair["shift"]
+    valid, u, v, level = projected_queries(pair["ka"], (sx, sy), pair["sf"], 7)
+    radius = (th * pair["sf"][level]).astype(np.float32)
+    desc = synth.perturb_descriptors(pair["da"], 9, 25)
+    r = np.random.default_rng(8)
+    kur = np.where(r.uniform(size=len(pair["kb"])) < 0.5, pair["kb"]["x"] - 8, -1).astype(np.float32)
+    qur = (u - 8 + r.normal(0, 1, len(u))).astype(np.float32)
+    isg = (1.0 / pair["sf"] ** 2).astype(np.float32)
+    bi, bd = matcher.window_best(gb, valid, u, v, radius, level, desc, chi2, kur, qur, isg)
+    oi, od = oracle.window_best(ob, valid, u, v, radius, level, desc, chi2, kur, qur, isg)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od)
+    assert (bi >= 0).sum() > 100
+    assert np.all(bd[bi < 0] == 256)
+
+
+def test_search_by_sim3(oracle, pair, matcher):
+    ga, gb, oa, ob = frames(pair, oracle)
+    sx, sy = pair["shift"]
+    v12, u12, w12, l12 = projected_queries(pair["ka"], (sx, sy), pair["sf"], 11)
+    v21, u21, w21, l21 = projected_queries(pair["kb"], (-sx, -sy), pair["sf"], 12)
+    q12 = (v12, u12, w12, (7.5 * pair["sf"][l12]).astype(np.float32), l12, synth.perturb_descriptors(pair["da"], 13, 20))
+    q21 = (v21, u21, w21, (7.5 * pair["sf"][l21]).astype(np.float32), l21, synth.perturb_descriptors(pair["db"], 14, 20))
+    n, m12 = matcher.SearchBySim3(ga, gb, q12, q21)
+    on, o12 = oracle.search_by_sim3(oa, ob, q12, q21)
+    assert n == on and np.array_equal(m12, o12)
+    assert n > 100
