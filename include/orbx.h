@@ -329,6 +329,16 @@ int orbm_search_by_sim3(orbm_context* m, const orbm_frame* kf1, const orbm_frame
                         const float* u21, const float* v21, const float* r21, const int32_t* level21,
                         const uint8_t* mp_desc2, int32_t* match12, int* nfound, int mem_space);
 
+/* MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:279-341) for a batch of
+ * map points: group g owns descriptors group_start[g] .. group_start[g+1] of desc (the rows
+ * vDescriptors collected at :296-302; total_desc rows in all).  best[g] = BestIdx inside the
+ * group (-1 for an empty group, which the reference leaves untouched, :303-304);
+ * best_median[g] (may be NULL) = BestMedian; out_desc (may be NULL, ngroups x 32) receives
+ * vDescriptors[BestIdx].  A group may hold at most 4096 descriptors. */
+int orbm_distinctive_descriptors(orbm_context* m, const uint8_t* desc, const int32_t* group_start,
+                                 int ngroups, int32_t* best, int32_t* best_median, uint8_t* out_desc,
+                                 int total_desc, int mem_space);
+
 /* Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for a rectified pair.
  * left/right: mvKeys / mDescriptors and mvKeysRight / mDescriptorsRight (the grid bounds of
  * orbm_frame are not read).  pyr_left / pyr_right: mvImagePyramid of the two extractors

@@ -743,4 +743,40 @@ int oracle_search_by_sim3(const oracle_frame* kf1, const oracle_frame* kf2, cons
     return nFound;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors for a batch of map points (reference
+// src/MapPoint.cc:307-340): group g owns the descriptors group_start[g] .. group_start[g+1]
+// (vDescriptors of one map point, bad keyframes already skipped); best[g] = BestIdx within the
+// group, -1 for an empty group (:303-304 returns without touching the descriptor).
+void oracle_distinctive_descriptors(const uint8_t* desc, const int* group_start, int ngroups, int* best, int* best_median) {
+    for (int g = 0; g < ngroups; g++) {
+        const uint8_t* D = desc + (size_t)group_start[g] * 32;
+        const size_t N = (size_t)(group_start[g + 1] - group_start[g]);
+        best[g] = -1;
+        if (best_median) best_median[g] = INT_MAX;
+        if (N == 0) continue;
+        std::vector<float> Distances(N * N);
+        for (size_t i = 0; i < N; i++) {
+            Distances[i * N + i] = 0;
+            for (size_t j = i + 1; j < N; j++) {
+                int distij = descriptor_distance(D + i * 32, D + j * 32);
+                Distances[i * N + j] = distij;
+                Distances[j * N + i] = distij;
+            }
+        }
+        int BestMedian = INT_MAX;
+        int BestIdx = 0;
+        for (size_t i = 0; i < N; i++) {
+            std::vector<int> vDists(Distances.begin() + i * N, Distances.begin() + i * N + N);
+            std::sort(vDists.begin(), vDists.end());
+            int median = vDists[0.5 * (N - 1)];
+            if (median < BestMedian) {
+                BestMedian = median;
+                BestIdx = i;
+            }
+        }
+        best[g] = BestIdx;
+        if (best_median) best_median[g] = BestMedian;
+    }
+}
+
 }  // extern "C"

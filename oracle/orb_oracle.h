@@ -156,6 +156,8 @@ void oracle_window_best(const oracle_frame* kf, int n, const uint8_t* valid, con
                         const float* radius, const int* level, const uint8_t* desc, int chi2_gate,
                         const float* kf_u_right, const float* q_u_right, const float* inv_level_sigma2, int* best_idx,
                         int* best_dist);
+/* MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:279-341), batched. */
+void oracle_distinctive_descriptors(const uint8_t* desc, const int* group_start, int ngroups, int* best, int* best_median);
 int oracle_search_by_sim3(const oracle_frame* kf1, const oracle_frame* kf2, const uint8_t* valid12, const float* u12,
                           const float* v12, const float* r12, const int* level12, const uint8_t* desc1,
                           const uint8_t* valid21, const float* u21, const float* v21, const float* r21,

@@ -406,3 +406,15 @@ def search_by_sim3(kf1, kf2, q12, q21):
     fn.restype = C.c_int
     n = fn(C.byref(kf1.c), C.byref(kf2.c), *[_p(x) for x in a], *[_p(x) for x in b], _p(m12))
     return n, m12[:kf1.n]
+
+
+def distinctive_descriptors(desc, group_start):
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    gs = np.ascontiguousarray(group_start, np.int32)
+    g = len(gs) - 1
+    best = np.full(max(g, 1), -1, np.int32)
+    med = np.zeros(max(g, 1), np.int32)
+    fn = lib().oracle_distinctive_descriptors
+    fn.restype = None
+    fn(_p(d), _p(gs), C.c_int(g), _p(best), _p(med))
+    return best[:g], med[:g]

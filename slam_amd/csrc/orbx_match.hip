@@ -908,6 +908,58 @@ __global__ __launch_bounds__(256) void k_sim3_agree(int n1, int n2, const int* _
     if (threadIdx.x == 0) *nFound = total;
 }
 
+// ------------------------------------------------------------------ distinctive descriptors
+// MapPoint::ComputeDistinctiveDescriptors for many map points (reference
+// src/MapPoint.cc:307-340): one wave per map point.  Row i of the distance matrix is formed
+// by the 64 lanes (kept in LDS as 16-bit values); its median, element (N-1)/2 of the sorted
+// row, is the smallest value v with at least (N-1)/2 + 1 entries <= v, found by bisection
+// over [0, 256] with wave ballots.  The first row with the smallest median wins.
+#define DD_MAX_GROUP 4096
+
+__global__ __launch_bounds__(256) void k_distinctive(const u8* __restrict__ desc, const int* __restrict__ groupStart,
+                                                      int ngroups, int* best, int* bestMedian, u8* outDesc) {
+    extern __shared__ u16 ddRows[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wv;
+    if (g >= ngroups) return;
+    u16* row = ddRows + wv * DD_MAX_GROUP;
+    const int b = groupStart[g], N = groupStart[g + 1] - b;
+    int bestIdx = -1, bestMed = 0x7fffffff;
+    if (N > 0 && N <= DD_MAX_GROUP) {
+        const int k = (N - 1) >> 1;
+        for (int i = 0; i < N; i++) {
+            const uint4* di = (const uint4*)(desc + (i64)(b + i) * 32);
+            const uint4 a0 = di[0], a1 = di[1];
+            for (int j = lane; j < N; j += 64) {
+                const uint4* dj = (const uint4*)(desc + (i64)(b + j) * 32);
+                row[j] = (u16)hamming256(a0, a1, dj[0], dj[1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            int lo = 0, hi = 256;  // smallest v with count(row <= v) >= k + 1
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                int cnt = 0;
+                for (int j0 = 0; j0 < N; j0 += 64) {
+                    const int j = j0 + lane;
+                    cnt += __popcll(__ballot(j < N && (int)row[j] <= mid));
+                }
+                if (cnt >= k + 1) hi = mid;
+                else lo = mid + 1;
+            }
+            if (lo < bestMed) {
+                bestMed = lo;
+                bestIdx = i;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0) {
+        best[g] = bestIdx;
+        if (bestMedian) bestMedian[g] = bestMed;
+    }
+    if (outDesc && bestIdx >= 0 && lane < 8) ((u32*)(outDesc + (i64)g * 32))[lane] = ((const u32*)(desc + (i64)(b + bestIdx) * 32))[lane];
+}
+
 // ------------------------------------------------------------------ stereo
 // Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for a rectified
 // pair.  The reference's per-row candidate lists are replaced by a direct scan:
@@ -1255,7 +1307,7 @@ enum {
     SL_KNN_Q, SL_KNN_T, SL_KNN_I, SL_KNN_D, SL_KNN_S, SL_KNN_I2, SL_KNN_D2, SL_KNN_S2, SL_ST_ROWS, SL_ST_SAD,
     SL_ST_U, SL_ST_D, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, SL_BW_VALID1,
     SL_BW_VALID2, SL_BW_M12, SL_BW_M21, SL_BW_BIN, SL_BW_HIST, SL_BW_UR1, SL_BW_UR2, SL_WB_LEVEL, SL_WB_IDX, SL_WB_DIST,
-    SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2
+    SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2, SL_DD_DESC, SL_DD_START, SL_DD_BEST, SL_DD_MED, SL_DD_OUT
 };
 
 // Device view of a caller array: the pointer itself for device memory, else a staged copy.
@@ -2014,6 +2066,53 @@ int orbm_search_by_sim3(orbm_context* m, const orbm_frame* kf1, const orbm_frame
     if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
     ORBX_HIP_CHECK(hipMemcpyAsync(nfound, dCount, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_distinctive_descriptors(orbm_context* m, const uint8_t* desc, const int32_t* group_start, int ngroups,
+                                 int32_t* best, int32_t* best_median, uint8_t* out_desc, int total_desc, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (ngroups < 0 || total_desc < 0 || !group_start || !best || (total_desc > 0 && !desc)) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (ngroups == 0) return ORBX_OK;
+    if (mem_space == ORBX_MEM_HOST) {
+        for (int g = 0; g < ngroups; g++) {
+            const int n = group_start[g + 1] - group_start[g];
+            if (group_start[g] < 0 || n < 0 || group_start[g + 1] > total_desc) {
+                orbx_set_error("group %d has bad bounds", g);
+                return ORBX_ERR_INVALID;
+            }
+            if (n > DD_MAX_GROUP) {
+                orbx_set_error("group %d has %d descriptors; limit is %d", g, n, DD_MAX_GROUP);
+                return ORBX_ERR_UNSUPPORTED;
+            }
+        }
+    }
+    const u8* dDesc;
+    const int* dStart;
+    if ((rc = stage_in(m, SL_DD_DESC, desc, (size_t)total_desc * 32, mem_space, &dDesc))) return rc;
+    if ((rc = stage_in(m, SL_DD_START, (const int*)group_start, (size_t)ngroups + 1, mem_space, &dStart))) return rc;
+    int *dBest, *dMed = nullptr;
+    u8* dOut = nullptr;
+    if ((rc = stage_out(m, SL_DD_BEST, (int*)best, (size_t)ngroups, mem_space, &dBest))) return rc;
+    if (best_median && (rc = stage_out(m, SL_DD_MED, (int*)best_median, (size_t)ngroups, mem_space, &dMed))) return rc;
+    if (out_desc && (rc = stage_out(m, SL_DD_OUT, out_desc, (size_t)ngroups * 32, mem_space, &dOut))) return rc;
+    static bool attrSet = false;
+    const int ldsBytes = 4 * DD_MAX_GROUP * (int)sizeof(u16);
+    if (!attrSet) {
+        ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_distinctive, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+        attrSet = true;
+    }
+    hipLaunchKernelGGL(k_distinctive, dim3((ngroups + 3) / 4), dim3(256), ldsBytes, m->stream, dDesc, dStart, ngroups, dBest,
+                       dMed, dOut);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)best, (const int*)dBest, (size_t)ngroups, mem_space))) return rc;
+    if (best_median && (rc = copy_back(m, (int*)best_median, (const int*)dMed, (size_t)ngroups, mem_space))) return rc;
+    if (out_desc && (rc = copy_back(m, out_desc, (const u8*)dOut, (size_t)ngroups * 32, mem_space))) return rc;
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }
 

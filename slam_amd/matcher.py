@@ -316,6 +316,19 @@ class ORBmatcher:
                                             *[x.ctypes.data for x in b], m12.ctypes.data, C.addressof(n), MEM_HOST))
         return n.value, m12[:len(KF1.kps)]
 
+    def ComputeDistinctiveDescriptors(self, desc, group_start):
+        """MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:279-341) for a batch:
+        returns (best index per group, best median per group, chosen descriptors (G, 32))."""
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        gs = np.ascontiguousarray(group_start, np.int32)
+        g = len(gs) - 1
+        best = np.full(max(g, 1), -1, np.int32)
+        med = np.zeros(max(g, 1), np.int32)
+        out = np.zeros((max(g, 1), 32), np.uint8)
+        check(self._lib.orbm_distinctive_descriptors(self._m, d.ctypes.data, gs.ctypes.data, g, best.ctypes.data,
+                                                     med.ctypes.data, out.ctypes.data, len(d), MEM_HOST))
+        return best[:g], med[:g], out[:g]
+
     # ---- stereo
     @staticmethod
     def pyramid_of(extractor, frame=0):

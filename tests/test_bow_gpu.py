@@ -180,3 +180,29 @@ def test_search_by_sim3(oracle, pair, matcher):
     on, o12 = oracle.search_by_sim3(oa, ob, q12, q21)
     assert n == on and np.array_equal(m12, o12)
     assert n > 100
+
+
+def test_distinctive_descriptors(oracle, matcher):
+    # groups of 0..130 observations: noisy copies of one descriptor per map point plus outliers
+    r = np.random.default_rng(17)
+    sizes = [0, 1, 2, 3, 4, 5, 7, 8, 16, 31, 63, 64, 65, 100, 130] + list(r.integers(1, 40, 200))
+    rows = []
+    start = [0]
+    for g, n in enumerate(sizes):
+        base = synth.synth_descriptors(1, 1000 + g)
+        blk = np.repeat(base, n, axis=0) if n else np.zeros((0, 32), np.uint8)
+        if n:
+            blk = synth.perturb_descriptors(blk, 2000 + g, 40)
+            out = r.uniform(size=n) < 0.15
+            blk[out] = synth.synth_descriptors(int(out.sum()), 3000 + g)
+        rows.append(blk)
+        start.append(start[-1] + n)
+    desc = np.concatenate(rows)
+    best, med, chosen = matcher.ComputeDistinctiveDescriptors(desc, start)
+    obest, omed = oracle.distinctive_descriptors(desc, start)
+    assert np.array_equal(best, obest)
+    assert np.array_equal(med[obest >= 0], omed[obest >= 0])
+    for g in range(len(sizes)):
+        if obest[g] >= 0:
+            assert np.array_equal(chosen[g], desc[start[g] + obest[g]])
+    assert best[0] == -1 and best[1] == 0
