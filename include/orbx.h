@@ -329,6 +329,26 @@ int orbm_search_by_sim3(orbm_context* m, const orbm_frame* kf1, const orbm_frame
                         const float* u21, const float* v21, const float* r21, const int32_t* level21,
                         const uint8_t* mp_desc2, int32_t* match12, int* nfound, int mem_space);
 
+/* Dynamic-object keypoint filter of the RGB-D frame constructor (reference
+ * perfect/src/Frame.cc:357-374): when the sum of the mask bytes exceeds 0.65 * w * h, only the
+ * keypoints whose mask byte at (int(pt.y), int(pt.x)) equals 1 are kept, in order; otherwise
+ * all are kept.  mask: 8-bit image in the call's memory space.  out arrays have room for n
+ * keypoints; *n_out (host memory) = the number kept.  Keypoints outside the mask image are
+ * dropped (the reference reads out of bounds there). */
+int orbm_filter_by_mask(orbm_context* m, const orbx_keypoint* kps, const uint8_t* desc, int n,
+                        const uint8_t* mask, int w, int h, size_t stride, orbx_keypoint* out_kps,
+                        uint8_t* out_desc, int* n_out, int mem_space);
+
+/* Keypoint records of the binary map file (reference perfect/src/Map.cc:361-380 write,
+ * :169-187 read): per keypoint pt.x, pt.y, size, angle, response (float), octave (int), the 32
+ * descriptor bytes, the map point index (unsigned long; ULONG_MAX = none): 64 bytes, in
+ * keypoint order.  mp_index may be NULL (pack: every index ULONG_MAX; unpack: not returned).
+ * Unpacked keypoints get class_id = -1, cv::KeyPoint's default. */
+int orbm_pack_keyframe_records(orbm_context* m, const orbx_keypoint* kps, const uint8_t* desc,
+                               const uint64_t* mp_index, int n, uint8_t* records, int mem_space);
+int orbm_unpack_keyframe_records(orbm_context* m, const uint8_t* records, int n, orbx_keypoint* kps,
+                                 uint8_t* desc, uint64_t* mp_index, int mem_space);
+
 /* MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:279-341) for a batch of
  * map points: group g owns descriptors group_start[g] .. group_start[g+1] of desc (the rows
  * vDescriptors collected at :296-302; total_desc rows in all).  best[g] = BestIdx inside the

@@ -779,4 +779,68 @@ void oracle_distinctive_descriptors(const uint8_t* desc, const int* group_start,
     }
 }
 
+// Dynamic-object keypoint filter of the RGB-D constructor (reference perfect/src/Frame.cc:357-374):
+// when the mask covers more than 65 % of the image (sum of its bytes), keep only keypoints
+// whose mask byte is 1, in order; otherwise everything stays.  Returns the new count.
+int oracle_filter_by_mask(const oracle_keypoint* kps, const uint8_t* desc, int n, const uint8_t* mask, int w, int h,
+                          size_t stride, oracle_keypoint* out_kps, uint8_t* out_desc) {
+    double s = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) s += mask[(size_t)y * stride + x];
+    int m = 0;
+    if (s > h * w * 0.65) {
+        for (int i = 0; i < n; i++) {
+            int val = (int)mask[(size_t)(int)kps[i].y * stride + (int)kps[i].x];
+            if (val == 1) {
+                out_kps[m] = kps[i];
+                memcpy(out_desc + (size_t)m * 32, desc + (size_t)i * 32, 32);
+                m++;
+            }
+        }
+    } else {
+        for (int i = 0; i < n; i++) {
+            out_kps[i] = kps[i];
+            memcpy(out_desc + (size_t)i * 32, desc + (size_t)i * 32, 32);
+        }
+        m = n;
+    }
+    return m;
+}
+
+// Keypoint records of the binary map file (reference perfect/src/Map.cc:361-380 write,
+// :169-187 read): per keypoint pt.x, pt.y, size, angle, response (float), octave (int), the 32
+// descriptor bytes and the map point index (unsigned long, ULONG_MAX = none): 64 bytes.
+void oracle_pack_keyframe_records(const oracle_keypoint* kps, const uint8_t* desc, const uint64_t* mp_index, int n,
+                                  uint8_t* records) {
+    uint8_t* p = records;
+    for (int i = 0; i < n; i++) {
+        memcpy(p, &kps[i].x, 4); p += 4;
+        memcpy(p, &kps[i].y, 4); p += 4;
+        memcpy(p, &kps[i].size, 4); p += 4;
+        memcpy(p, &kps[i].angle, 4); p += 4;
+        memcpy(p, &kps[i].response, 4); p += 4;
+        memcpy(p, &kps[i].octave, 4); p += 4;
+        for (int j = 0; j < 32; j++) *p++ = desc[(size_t)i * 32 + j];
+        const uint64_t idx = mp_index ? mp_index[i] : ~0ull;
+        memcpy(p, &idx, 8); p += 8;
+    }
+}
+
+void oracle_unpack_keyframe_records(const uint8_t* records, int n, oracle_keypoint* kps, uint8_t* desc, uint64_t* mp_index) {
+    const uint8_t* p = records;
+    for (int i = 0; i < n; i++) {
+        oracle_keypoint kp;
+        kp.class_id = -1;  // cv::KeyPoint's default
+        memcpy(&kp.x, p, 4); p += 4;
+        memcpy(&kp.y, p, 4); p += 4;
+        memcpy(&kp.size, p, 4); p += 4;
+        memcpy(&kp.angle, p, 4); p += 4;
+        memcpy(&kp.response, p, 4); p += 4;
+        memcpy(&kp.octave, p, 4); p += 4;
+        kps[i] = kp;
+        for (int j = 0; j < 32; j++) desc[(size_t)i * 32 + j] = *p++;
+        memcpy(&mp_index[i], p, 8); p += 8;
+    }
+}
+
 }  // extern "C"

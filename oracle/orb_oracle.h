@@ -156,6 +156,12 @@ void oracle_window_best(const oracle_frame* kf, int n, const uint8_t* valid, con
                         const float* radius, const int* level, const uint8_t* desc, int chi2_gate,
                         const float* kf_u_right, const float* q_u_right, const float* inv_level_sigma2, int* best_idx,
                         int* best_dist);
+/* perfect/src/Frame.cc:357-374 (mask filter) and perfect/src/Map.cc:361-380, :169-187 (map file records). */
+int oracle_filter_by_mask(const oracle_keypoint* kps, const uint8_t* desc, int n, const uint8_t* mask, int w, int h,
+                          size_t stride, oracle_keypoint* out_kps, uint8_t* out_desc);
+void oracle_pack_keyframe_records(const oracle_keypoint* kps, const uint8_t* desc, const uint64_t* mp_index, int n,
+                                  uint8_t* records);
+void oracle_unpack_keyframe_records(const uint8_t* records, int n, oracle_keypoint* kps, uint8_t* desc, uint64_t* mp_index);
 /* MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:279-341), batched. */
 void oracle_distinctive_descriptors(const uint8_t* desc, const int* group_start, int ngroups, int* best, int* best_median);
 int oracle_search_by_sim3(const oracle_frame* kf1, const oracle_frame* kf2, const uint8_t* valid12, const float* u12,

@@ -418,3 +418,39 @@ def distinctive_descriptors(desc, group_start):
     fn.restype = None
     fn(_p(d), _p(gs), C.c_int(g), _p(best), _p(med))
     return best[:g], med[:g]
+
+
+def filter_by_mask(kps, desc, mask):
+    k = np.ascontiguousarray(kps, KP_DTYPE)
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    m = np.ascontiguousarray(mask, np.uint8)
+    ok = np.zeros(max(len(k), 1), KP_DTYPE)
+    od = np.zeros((max(len(k), 1), 32), np.uint8)
+    fn = lib().oracle_filter_by_mask
+    fn.restype = C.c_int
+    n = fn(_p(k), _p(d), C.c_int(len(k)), _p(m), C.c_int(m.shape[1]), C.c_int(m.shape[0]), C.c_size_t(m.strides[0]),
+           _p(ok), _p(od))
+    return ok[:n].copy(), od[:n].copy()
+
+
+def pack_keyframe_records(kps, desc, mp_index):
+    k = np.ascontiguousarray(kps, KP_DTYPE)
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    mi = None if mp_index is None else np.ascontiguousarray(mp_index, np.uint64)
+    rec = np.zeros(max(len(k), 1) * 64, np.uint8)
+    fn = lib().oracle_pack_keyframe_records
+    fn.restype = None
+    fn(_p(k), _p(d), None if mi is None else _p(mi), C.c_int(len(k)), _p(rec))
+    return rec[:len(k) * 64]
+
+
+def unpack_keyframe_records(rec):
+    r = np.ascontiguousarray(rec, np.uint8)
+    n = len(r) // 64
+    k = np.zeros(max(n, 1), KP_DTYPE)
+    d = np.zeros((max(n, 1), 32), np.uint8)
+    mi = np.zeros(max(n, 1), np.uint64)
+    fn = lib().oracle_unpack_keyframe_records
+    fn.restype = None
+    fn(_p(r), C.c_int(n), _p(k), _p(d), _p(mi))
+    return k[:n], d[:n], mi[:n]

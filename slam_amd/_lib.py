@@ -114,6 +114,9 @@ SIGNATURES = {
                               _i]),
     "orbm_search_by_sim3": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _i]),
+    "orbm_filter_by_mask": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _sz, _vp, _vp, _vp, _i]),
+    "orbm_pack_keyframe_records": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i]),
+    "orbm_unpack_keyframe_records": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i]),
     "orbm_distinctive_descriptors": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
     "orbm_compute_stereo_matches": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), C.POINTER(Pyramid),
                                          C.POINTER(Pyramid), _vp, _vp, _f, _f, _vp, _vp, _vp, _i]),

@@ -960,6 +960,89 @@ __global__ __launch_bounds__(256) void k_distinctive(const u8* __restrict__ desc
     if (outDesc && bestIdx >= 0 && lane < 8) ((u32*)(outDesc + (i64)g * 32))[lane] = ((const u32*)(desc + (i64)(b + bestIdx) * 32))[lane];
 }
 
+// ------------------------------------------------------------------ mask filter, map records
+// Sum of the mask bytes (reference perfect/src/Frame.cc:357): the whole job of one launch.
+__global__ __launch_bounds__(256) void k_mask_sum(const u8* __restrict__ mask, int w, int h, i64 stride, u64* sum) {
+    u64 acc = 0;
+    for (int y = blockIdx.x; y < h; y += gridDim.x) {
+        const u8* row = mask + (i64)y * stride;
+        for (int x = threadIdx.x; x < w; x += 256) acc += row[x];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
+}
+
+// Stable compaction of the keypoints whose mask byte is 1 (reference
+// perfect/src/Frame.cc:358-373); one workgroup, keypoints in index order.
+__global__ __launch_bounds__(1024) void k_mask_filter(const orbx_keypoint* __restrict__ kps, const u8* __restrict__ desc, int n,
+                                                       const u8* __restrict__ mask, int w, int h, i64 stride,
+                                                       const u64* __restrict__ sum, orbx_keypoint* outKps, u8* outDesc,
+                                                       int* nOut) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool active = (double)*sum > (double)h * (double)w * 0.65;  // h * w * 0.65 as the reference forms it
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        bool keep = false;
+        orbx_keypoint kp;
+        if (i < n) {
+            kp = kps[i];
+            if (active) {
+                const int px = (int)kp.x, py = (int)kp.y;
+                keep = px >= 0 && px < w && py >= 0 && py < h && mask[(i64)py * stride + px] == 1;
+            } else {
+                keep = true;
+            }
+        }
+        int tot;
+        const int off = wave_excl_count(keep, &tot);
+        if (lane == 0) wsum[wv] = tot;
+        __syncthreads();
+        int pre = carry;
+        for (int k = 0; k < wv; k++) pre += wsum[k];
+        if (keep) {
+            const int o = pre + off;
+            outKps[o] = kp;
+            const uint4* s = (const uint4*)(desc + (i64)i * 32);
+            uint4* d = (uint4*)(outDesc + (i64)o * 32);
+            d[0] = s[0];
+            d[1] = s[1];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int k = 0; k < 16; k++) t += wsum[k];
+            carry += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *nOut = carry;
+}
+
+// 64-byte keypoint records of the binary map file (reference perfect/src/Map.cc:361-380,
+// :169-187): 16 lanes move one record, 4 bytes each.
+__global__ __launch_bounds__(256) void k_records(int pack, int n, orbx_keypoint* kps, u8* desc, u64* mpIndex, u8* records) {
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 i = t >> 4;
+    const int wd = (int)(t & 15);
+    if (i >= n) return;
+    u32* rec = (u32*)(records + i * 64) + wd;
+    u32* src;
+    if (wd < 6) src = (u32*)(kps + i) + wd;                       // pt.x, pt.y, size, angle, response, octave
+    else if (wd < 14) src = (u32*)(desc + i * 32) + (wd - 6);      // descriptor
+    else src = mpIndex ? (u32*)(mpIndex + i) + (wd - 14) : nullptr;  // map point index
+    if (pack) {
+        *rec = src ? *src : 0xFFFFFFFFu;  // no index array: ULONG_MAX
+    } else {
+        if (src) *src = *rec;
+        if (wd == 0) kps[i].class_id = -1;  // cv::KeyPoint's default
+    }
+}
+
 // ------------------------------------------------------------------ stereo
 // Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for a rectified
 // pair.  The reference's per-row candidate lists are replaced by a direct scan:
@@ -1307,7 +1390,8 @@ enum {
     SL_KNN_Q, SL_KNN_T, SL_KNN_I, SL_KNN_D, SL_KNN_S, SL_KNN_I2, SL_KNN_D2, SL_KNN_S2, SL_ST_ROWS, SL_ST_SAD,
     SL_ST_U, SL_ST_D, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, SL_BW_VALID1,
     SL_BW_VALID2, SL_BW_M12, SL_BW_M21, SL_BW_BIN, SL_BW_HIST, SL_BW_UR1, SL_BW_UR2, SL_WB_LEVEL, SL_WB_IDX, SL_WB_DIST,
-    SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2, SL_DD_DESC, SL_DD_START, SL_DD_BEST, SL_DD_MED, SL_DD_OUT
+    SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2, SL_DD_DESC, SL_DD_START, SL_DD_BEST, SL_DD_MED, SL_DD_OUT,
+    SL_MK_MASK, SL_MK_KPS, SL_MK_DESC, SL_RC_REC, SL_RC_IDX
 };
 
 // Device view of a caller array: the pointer itself for device memory, else a staged copy.
@@ -2112,6 +2196,92 @@ int orbm_distinctive_descriptors(orbm_context* m, const uint8_t* desc, const int
     if ((rc = copy_back(m, (int*)best, (const int*)dBest, (size_t)ngroups, mem_space))) return rc;
     if (best_median && (rc = copy_back(m, (int*)best_median, (const int*)dMed, (size_t)ngroups, mem_space))) return rc;
     if (out_desc && (rc = copy_back(m, out_desc, (const u8*)dOut, (size_t)ngroups * 32, mem_space))) return rc;
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_filter_by_mask(orbm_context* m, const orbx_keypoint* kps, const uint8_t* desc, int n, const uint8_t* mask, int w,
+                        int h, size_t stride, orbx_keypoint* out_kps, uint8_t* out_desc, int* n_out, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (n < 0 || w < 1 || h < 1 || stride < (size_t)w || !mask || !n_out || (n > 0 && (!kps || !desc || !out_kps || !out_desc))) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    const orbx_keypoint* dKps;
+    const u8 *dDesc, *dMask;
+    if ((rc = stage_in(m, SL_F1_KPS, kps, (size_t)n, mem_space, &dKps))) return rc;
+    if ((rc = stage_in(m, SL_F1_DESC, desc, (size_t)n * 32, mem_space, &dDesc))) return rc;
+    if ((rc = stage_in(m, SL_MK_MASK, mask, stride * (size_t)h, mem_space, &dMask))) return rc;
+    orbx_keypoint* dOutK;
+    u8* dOutD;
+    if ((rc = stage_out(m, SL_MK_KPS, out_kps, (size_t)n, mem_space, &dOutK))) return rc;
+    if ((rc = stage_out(m, SL_MK_DESC, out_desc, (size_t)n * 32, mem_space, &dOutD))) return rc;
+    void* dScal;
+    if ((rc = pool_get(m, SL_SCALAR, 64, &dScal))) return rc;
+    ORBX_HIP_CHECK(hipMemsetAsync(dScal, 0, 64, m->stream));
+    hipLaunchKernelGGL(k_mask_sum, dim3(std::min(h, 1024)), dim3(256), 0, m->stream, dMask, w, h, (i64)stride, (u64*)dScal);
+    ORBX_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_mask_filter, dim3(1), dim3(1024), 0, m->stream, dKps, dDesc, n, dMask, w, h, (i64)stride,
+                       (const u64*)dScal, dOutK, dOutD, (int*)dScal + 4);
+    ORBX_HIP_CHECK(hipGetLastError());
+    ORBX_HIP_CHECK(hipMemcpyAsync(n_out, (int*)dScal + 4, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (mem_space == ORBX_MEM_HOST && *n_out > 0) {
+        ORBX_HIP_CHECK(hipMemcpy(out_kps, dOutK, (size_t)*n_out * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+        ORBX_HIP_CHECK(hipMemcpy(out_desc, dOutD, (size_t)*n_out * 32, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}
+
+int orbm_pack_keyframe_records(orbm_context* m, const orbx_keypoint* kps, const uint8_t* desc, const uint64_t* mp_index, int n,
+                               uint8_t* records, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!kps || !desc || !records))) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (n == 0) return ORBX_OK;
+    const orbx_keypoint* dKps;
+    const u8* dDesc;
+    const uint64_t* dIdx;
+    u8* dRec;
+    if ((rc = stage_in(m, SL_F1_KPS, kps, (size_t)n, mem_space, &dKps))) return rc;
+    if ((rc = stage_in(m, SL_F1_DESC, desc, (size_t)n * 32, mem_space, &dDesc))) return rc;
+    if ((rc = stage_in(m, SL_RC_IDX, mp_index, (size_t)n, mem_space, &dIdx))) return rc;
+    if ((rc = stage_out(m, SL_RC_REC, records, (size_t)n * 64, mem_space, &dRec))) return rc;
+    hipLaunchKernelGGL(k_records, dim3(((size_t)n * 16 + 255) / 256), dim3(256), 0, m->stream, 1, n, (orbx_keypoint*)dKps,
+                       (u8*)dDesc, (u64*)dIdx, dRec);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, records, (const u8*)dRec, (size_t)n * 64, mem_space))) return rc;
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+int orbm_unpack_keyframe_records(orbm_context* m, const uint8_t* records, int n, orbx_keypoint* kps, uint8_t* desc,
+                                 uint64_t* mp_index, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!kps || !desc || !records))) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (n == 0) return ORBX_OK;
+    const u8* dRec;
+    orbx_keypoint* dKps;
+    u8* dDesc;
+    uint64_t* dIdx = nullptr;
+    if ((rc = stage_in(m, SL_RC_REC, records, (size_t)n * 64, mem_space, &dRec))) return rc;
+    if ((rc = stage_out(m, SL_F1_KPS, kps, (size_t)n, mem_space, &dKps))) return rc;
+    if ((rc = stage_out(m, SL_F1_DESC, desc, (size_t)n * 32, mem_space, &dDesc))) return rc;
+    if (mp_index && (rc = stage_out(m, SL_RC_IDX, mp_index, (size_t)n, mem_space, &dIdx))) return rc;
+    hipLaunchKernelGGL(k_records, dim3(((size_t)n * 16 + 255) / 256), dim3(256), 0, m->stream, 0, n, dKps, dDesc, (u64*)dIdx,
+                       (u8*)dRec);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, kps, (const orbx_keypoint*)dKps, (size_t)n, mem_space))) return rc;
+    if ((rc = copy_back(m, desc, (const u8*)dDesc, (size_t)n * 32, mem_space))) return rc;
+    if (mp_index && (rc = copy_back(m, mp_index, (const uint64_t*)dIdx, (size_t)n, mem_space))) return rc;
     if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }

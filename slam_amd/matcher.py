@@ -329,6 +329,43 @@ class ORBmatcher:
                                                      med.ctypes.data, out.ctypes.data, len(d), MEM_HOST))
         return best[:g], med[:g], out[:g]
 
+    # ---- keypoint set utilities
+    def filter_by_mask(self, kps, desc, mask):
+        """Dynamic-object filter of reference perfect/src/Frame.cc:357-374: returns the kept
+        (keypoints, descriptors)."""
+        k = np.ascontiguousarray(kps, KP_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        mk = np.ascontiguousarray(mask, np.uint8)
+        ok = np.zeros(max(len(k), 1), KP_DTYPE)
+        od = np.zeros((max(len(k), 1), 32), np.uint8)
+        n = C.c_int(0)
+        check(self._lib.orbm_filter_by_mask(self._m, k.ctypes.data, d.ctypes.data, len(k), mk.ctypes.data, mk.shape[1],
+                                            mk.shape[0], mk.strides[0], ok.ctypes.data, od.ctypes.data, C.addressof(n),
+                                            MEM_HOST))
+        return ok[:n.value].copy(), od[:n.value].copy()
+
+    def pack_keyframe_records(self, kps, desc, mp_index=None):
+        """Keypoint records of the binary map file (reference perfect/src/Map.cc:361-380): (n*64,) uint8."""
+        k = np.ascontiguousarray(kps, KP_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        mi = None if mp_index is None else np.ascontiguousarray(mp_index, np.uint64)
+        rec = np.zeros(max(len(k), 1) * 64, np.uint8)
+        check(self._lib.orbm_pack_keyframe_records(self._m, k.ctypes.data, d.ctypes.data,
+                                                   None if mi is None else mi.ctypes.data, len(k), rec.ctypes.data,
+                                                   MEM_HOST))
+        return rec[:len(k) * 64]
+
+    def unpack_keyframe_records(self, records):
+        """Inverse of pack_keyframe_records (reference perfect/src/Map.cc:169-187)."""
+        r = np.ascontiguousarray(records, np.uint8)
+        n = len(r) // 64
+        k = np.zeros(max(n, 1), KP_DTYPE)
+        d = np.zeros((max(n, 1), 32), np.uint8)
+        mi = np.zeros(max(n, 1), np.uint64)
+        check(self._lib.orbm_unpack_keyframe_records(self._m, r.ctypes.data, n, k.ctypes.data, d.ctypes.data,
+                                                     mi.ctypes.data, MEM_HOST))
+        return k[:n], d[:n], mi[:n]
+
     # ---- stereo
     @staticmethod
     def pyramid_of(extractor, frame=0):

@@ -206,3 +206,31 @@ def test_distinctive_descriptors(oracle, matcher):
         if obest[g] >= 0:
             assert np.array_equal(chosen[g], desc[start[g] + obest[g]])
     assert best[0] == -1 and best[1] == 0
+
+
+def test_mask_filter_and_map_records(oracle, pair, matcher):
+    ka, da = pair["ka"], pair["da"]
+    mask = np.ones((480, 640), np.uint8)
+    mask[100:300, 200:420] = 0          # a moving object
+    mask[10:20, 10:20] = 2              # a value that is neither 0 nor 1
+    k, d = matcher.filter_by_mask(ka, da, mask)
+    ok, od = oracle.filter_by_mask(ka, da, mask)
+    assert k.tobytes() == ok.tobytes() and np.array_equal(d, od) and 0 < len(k) < len(ka)
+    small = np.zeros((480, 640), np.uint8)
+    small[:200] = 1                     # covers less than 65 %: nothing is filtered
+    k, d = matcher.filter_by_mask(ka, da, small)
+    ok, od = oracle.filter_by_mask(ka, da, small)
+    assert k.tobytes() == ok.tobytes() and len(k) == len(ka) and np.array_equal(d, od)
+    k, d = matcher.filter_by_mask(ka[:0], da[:0], mask)
+    assert len(k) == 0
+    # map file records
+    r = np.random.default_rng(2)
+    mi = r.integers(0, 5000, len(ka)).astype(np.uint64)
+    mi[r.uniform(size=len(ka)) < 0.4] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    rec = matcher.pack_keyframe_records(ka, da, mi)
+    assert np.array_equal(rec, oracle.pack_keyframe_records(ka, da, mi))
+    k2, d2, mi2 = matcher.unpack_keyframe_records(rec)
+    ok2, od2, omi2 = oracle.unpack_keyframe_records(rec)
+    assert k2.tobytes() == ok2.tobytes() and np.array_equal(d2, od2) and np.array_equal(mi2, omi2)
+    assert np.array_equal(d2, da) and np.array_equal(mi2, mi) and np.array_equal(k2["x"], ka["x"]) and np.all(k2["class_id"] == -1)
+    assert np.array_equal(matcher.pack_keyframe_records(ka, da, None), oracle.pack_keyframe_records(ka, da, None))
