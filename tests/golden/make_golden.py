@@ -96,6 +96,73 @@ def main():
                         mbf=np.float32(386.1448), n_left=len(kl), n_right=len(kr), n_stereo=n, u_right=ur, depth=dp)
     print("stereo", len(kl), len(kr), n)
 
+    make_bow_golden()
+
+
+def make_bow_golden():
+    """Vocabulary-guided searches, candidate loop, Sim3 agreement, distinctive descriptors, mask
+    filter and map records on one pair of views; inputs are stored with the expected outputs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_bow_gpu as T
+    p = O.params()
+    sf = O.tables(p)["scale"]
+    scene = synth.synth_image(700, 520, 91)
+    a = np.ascontiguousarray(scene[20:500, 30:670])
+    b = np.ascontiguousarray(scene[24:504, 18:658])
+    ka, da = O.extract(p, a)
+    kb, db = O.extract(p, b)
+    pair = dict(sf=sf, ka=ka, da=da, kb=kb, db=db, shift=(12.0, -4.0))
+    fa, fb = O.FrameData(ka, da, BOUNDS, sf), O.FrameData(kb, db, BOUNDS, sf)
+    fva = T.feature_vector(T.node_of(ka, 0, 0, 97, 1), 3)
+    fvb = T.feature_vector(T.node_of(kb, -12.0, 4.0, 97, 2), 4)
+
+    def csr(fv):
+        s, keep = O.feature_vector(fv)
+        return keep
+
+    r = np.random.default_rng(42)
+    valid1 = (r.uniform(size=len(ka)) < 0.8).astype(np.uint8)
+    valid2 = (r.uniform(size=len(kb)) < 0.7).astype(np.uint8)
+    bow_a = O.search_by_bow(fa, fva, valid1, fb, fvb, None, 50, 0.75, True)
+    bow_b = O.search_by_bow(fa, fva, valid1, fb, fvb, valid2, 49, 0.75, True)
+    has1 = (r.uniform(size=len(ka)) < 0.3).astype(np.uint8)
+    has2 = (r.uniform(size=len(kb)) < 0.3).astype(np.uint8)
+    ur1 = np.where(r.uniform(size=len(ka)) < 0.5, ka["x"] - 10, -1).astype(np.float32)
+    ur2 = np.where(r.uniform(size=len(kb)) < 0.5, kb["x"] - 10, -1).astype(np.float32)
+    F12 = np.array([[0, 0, -4.0], [0, 0, -12.0], [4.0, 12.0, 0]], np.float32).T.copy()
+    sigma2 = (sf ** 2).astype(np.float32)
+    tri = O.search_for_triangulation(fa, fva, has1, ur1, fb, fvb, has2, ur2, F12, 4320.0, -1093.0, sigma2, False, True)
+    v12, u12, w12, l12 = T.projected_queries(ka, (12.0, -4.0), sf, 11)
+    v21, u21, w21, l21 = T.projected_queries(kb, (-12.0, 4.0), sf, 12)
+    q12 = (v12, u12, w12, (7.5 * sf[l12]).astype(np.float32), l12, synth.perturb_descriptors(da, 13, 20))
+    q21 = (v21, u21, w21, (7.5 * sf[l21]).astype(np.float32), l21, synth.perturb_descriptors(db, 14, 20))
+    kur = np.where(r.uniform(size=len(kb)) < 0.5, kb["x"] - 8, -1).astype(np.float32)
+    qur = (u12 - 8).astype(np.float32)
+    isg = (1.0 / sf ** 2).astype(np.float32)
+    wb = O.window_best(fb, q12[0], q12[1], q12[2], q12[3], q12[4], q12[5], True, kur, qur, isg)
+    sim3 = O.search_by_sim3(fa, fb, q12, q21)
+    gs = np.concatenate([[0], np.cumsum(r.integers(0, 12, 80))]).astype(np.int32)
+    dd = synth.perturb_descriptors(np.repeat(synth.synth_descriptors(80, 5), np.diff(gs), axis=0), 6, 60)
+    dbest, dmed = O.distinctive_descriptors(dd, gs)
+    mask = np.ones((480, 640), np.uint8)
+    mask[120:330, 180:400] = 0
+    mk, md = O.filter_by_mask(ka, da, mask)
+    mi = r.integers(0, 9000, len(ka)).astype(np.uint64)
+    rec = O.pack_keyframe_records(ka, da, mi)
+    ia, sa, ta = csr(fva)
+    ib, sb, tb = csr(fvb)
+    np.savez_compressed(os.path.join(OUT, "bow_pair.npz"), ka=ka, da=da, kb=kb, db=db, sf=sf, fva_ids=ia, fva_start=sa,
+                        fva_items=ta, fvb_ids=ib, fvb_start=sb, fvb_items=tb, valid1=valid1, valid2=valid2,
+                        bow_a_n=bow_a[0], bow_a_12=bow_a[1], bow_a_21=bow_a[2], bow_b_n=bow_b[0], bow_b_12=bow_b[1],
+                        bow_b_21=bow_b[2], has1=has1, has2=has2, ur1=ur1, ur2=ur2, F12=F12, sigma2=sigma2, tri_n=tri[0],
+                        tri_12=tri[1], q12_valid=q12[0], q12_u=q12[1], q12_v=q12[2], q12_r=q12[3], q12_level=q12[4],
+                        q12_desc=q12[5], q21_valid=q21[0], q21_u=q21[1], q21_v=q21[2], q21_r=q21[3], q21_level=q21[4],
+                        q21_desc=q21[5], kur=kur, qur=qur, isg=isg, wb_idx=wb[0], wb_dist=wb[1], sim3_n=sim3[0],
+                        sim3_12=sim3[1], dd_start=gs, dd_desc=dd, dd_best=dbest, dd_med=dmed, mask_box=[120, 330, 180, 400],
+                        mask_kept=len(mk), mask_sha1=sha(np.concatenate([mk.view(np.uint8).ravel(), md.ravel()])),
+                        mp_index=mi, rec_sha1=sha(rec))
+    print("bow", bow_a[0], bow_b[0], tri[0], sim3[0])
+
 
 if __name__ == "__main__":
     main()

@@ -42,7 +42,7 @@ def same(k, d, z):
 
 def test_fixtures_exist():
     assert len(seeded_cases()) >= 5
-    for f in ("extract_small_stored.npz", "extract_low_contrast.npz", "match_pair.npz", "stereo_kitti.npz"):
+    for f in ("extract_small_stored.npz", "extract_low_contrast.npz", "match_pair.npz", "stereo_kitti.npz", "bow_pair.npz"):
         assert os.path.exists(os.path.join(G, f))
 
 
@@ -102,6 +102,68 @@ def test_oracle_reproduces_stereo(oracle):
     top = kl["y"][ur >= 0] < int(z["h"]) // 2 - 20
     bot = kl["y"][ur >= 0] > int(z["h"]) // 2 + 20
     assert abs(np.median(d[top]) - int(z["dtop"])) < 0.5 and abs(np.median(d[bot]) - int(z["dbot"])) < 0.5
+
+
+def fv_pairs(z, pre):
+    ids, start, items = z[pre + "_ids"], z[pre + "_start"], z[pre + "_items"]
+    return [(int(ids[i]), items[start[i]:start[i + 1]].tolist()) for i in range(len(ids))]
+
+
+def run_bow_case(z, api, fa, fb):
+    """api: dict of callables with the oracle's signatures; returns nothing, asserts equality."""
+    fva, fvb = fv_pairs(z, "fva"), fv_pairs(z, "fvb")
+    n, m12, m21 = api["bow"](fa, fva, z["valid1"], fb, fvb, None, 50, 0.75, True)
+    assert n == int(z["bow_a_n"]) and np.array_equal(m12, z["bow_a_12"]) and np.array_equal(m21, z["bow_a_21"])
+    n, m12, m21 = api["bow"](fa, fva, z["valid1"], fb, fvb, z["valid2"], 49, 0.75, True)
+    assert n == int(z["bow_b_n"]) and np.array_equal(m12, z["bow_b_12"]) and np.array_equal(m21, z["bow_b_21"])
+    n, m12 = api["tri"](fa, fva, z["has1"], z["ur1"], fb, fvb, z["has2"], z["ur2"], z["F12"], 4320.0, -1093.0, z["sigma2"],
+                        False, True)
+    assert n == int(z["tri_n"]) and np.array_equal(m12, z["tri_12"])
+    q12 = tuple(z["q12_" + k] for k in ("valid", "u", "v", "r", "level", "desc"))
+    q21 = tuple(z["q21_" + k] for k in ("valid", "u", "v", "r", "level", "desc"))
+    bi, bd = api["wb"](fb, *q12, True, z["kur"], z["qur"], z["isg"])
+    assert np.array_equal(bi, z["wb_idx"]) and np.array_equal(bd, z["wb_dist"])
+    n, m12 = api["sim3"](fa, fb, q12, q21)
+    assert n == int(z["sim3_n"]) and np.array_equal(m12, z["sim3_12"])
+    best, med = api["dd"](z["dd_desc"], z["dd_start"])[:2]
+    assert np.array_equal(best, z["dd_best"]) and np.array_equal(med[best >= 0], z["dd_med"][best >= 0])
+    mask = np.ones((480, 640), np.uint8)
+    y0, y1, x0, x1 = [int(v) for v in z["mask_box"]]
+    mask[y0:y1, x0:x1] = 0
+    mk, md = api["mask"](z["ka"], z["da"], mask)
+    assert len(mk) == int(z["mask_kept"])
+    assert sha(np.concatenate([np.ascontiguousarray(mk).view(np.uint8).ravel(), md.ravel()])) == str(z["mask_sha1"])
+    assert sha(api["pack"](z["ka"], z["da"], z["mp_index"])) == str(z["rec_sha1"])
+
+
+def test_oracle_reproduces_bow_family(oracle):
+    z = np.load(os.path.join(G, "bow_pair.npz"))
+    fa = oracle.FrameData(z["ka"], z["da"], BOUNDS, z["sf"])
+    fb = oracle.FrameData(z["kb"], z["db"], BOUNDS, z["sf"])
+    run_bow_case(z, dict(bow=oracle.search_by_bow, tri=oracle.search_for_triangulation, wb=oracle.window_best,
+                         sim3=oracle.search_by_sim3, dd=oracle.distinctive_descriptors, mask=oracle.filter_by_mask,
+                         pack=oracle.pack_keyframe_records), fa, fb)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_bow_family():
+    from slam_amd.matcher import FrameView, ORBmatcher
+    z = np.load(os.path.join(G, "bow_pair.npz"))
+    fa = FrameView(z["ka"], z["da"], BOUNDS, z["sf"])
+    fb = FrameView(z["kb"], z["db"], BOUNDS, z["sf"])
+    m = ORBmatcher(0.75, True)
+
+    def bow(f1, fv1, v1, f2, fv2, v2, max_dist, ratio, ori):
+        return m.SearchByBoW(f1, fv1, v1, f2, fv2, v2, keyframe_pair=(max_dist == 49))
+
+    def tri(f1, fv1, h1, u1, f2, fv2, h2, u2, F12, ex, ey, sigma2, only_stereo, ori):
+        return m.SearchForTriangulation(f1, fv1, h1, u1, f2, fv2, h2, u2, F12, ex, ey, sigma2, only_stereo)
+
+    try:
+        run_bow_case(z, dict(bow=bow, tri=tri, wb=m.window_best, sim3=m.SearchBySim3, dd=m.ComputeDistinctiveDescriptors,
+                             mask=m.filter_by_mask, pack=m.pack_keyframe_records), fa, fb)
+    finally:
+        m.close()
 
 
 @pytest.mark.gpu
