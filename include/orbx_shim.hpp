@@ -19,6 +19,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "orbx.h"
@@ -250,6 +251,100 @@ public:
                                                 mvDepth.data(), &n, ORBX_MEM_HOST),
                     "orbm_compute_stereo_matches");
         return n;
+    }
+
+    // A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) flattened for the C ABI.
+    struct FlatFeatureVector {
+        std::vector<uint32_t> ids, items;
+        std::vector<int32_t> start;
+        orbm_feature_vector c() const {
+            orbm_feature_vector f;
+            f.n_nodes = (int32_t)ids.size();
+            f.n_items = (int32_t)items.size();
+            f.node_ids = ids.data();
+            f.start = start.data();
+            f.items = items.data();
+            return f;
+        }
+    };
+    template <typename MapT>
+    static FlatFeatureVector Flatten(const MapT& fv) {
+        FlatFeatureVector o;
+        o.start.push_back(0);
+        for (typename MapT::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+            o.ids.push_back((uint32_t)it->first);
+            for (size_t k = 0; k < it->second.size(); k++) o.items.push_back((uint32_t)it->second[k]);
+            o.start.push_back((int32_t)o.items.size());
+        }
+        return o;
+    }
+
+    // reference src/ORBmatcher.cc:209-355 (keyframePair = false; F2 is the frame) and :642-788
+    // (keyframePair = true; valid2 required).  valid1[i]: keypoint i of the first keyframe holds a
+    // good map point.  match12[i1] = keypoint of the second view or -1; match21 is its inverse
+    // (vpMapPointMatches of the first overload, by index).
+    template <typename MapT>
+    int SearchByBoW(const FrameView& KF1, const MapT& featVec1, const unsigned char* valid1, const FrameView& F2,
+                    const MapT& featVec2, const unsigned char* valid2, bool keyframePair, std::vector<int>& match12,
+                    std::vector<int>& match21) {
+        match12.assign(KF1.N, -1);
+        match21.assign(F2.N, -1);
+        const FlatFeatureVector a = Flatten(featVec1), b = Flatten(featVec2);
+        const orbm_feature_vector ca = a.c(), cb = b.c();
+        orbm_frame f1 = KF1.c(), f2 = F2.c();
+        int n = 0;
+        orbx::check(orbm_search_by_bow(m_, &f1, &ca, valid1, &f2, &cb, valid2, keyframePair ? TH_LOW - 1 : TH_LOW, mfNNratio,
+                                       mbCheckOrientation, match12.data(), match21.data(), &n, ORBX_MEM_HOST),
+                    "orbm_search_by_bow");
+        return n;
+    }
+
+    // reference src/ORBmatcher.cc:803-992; ex, ey and F12 (row-major 3x3) from :809-818 and the caller.
+    template <typename MapT>
+    int SearchForTriangulation(const FrameView& KF1, const MapT& featVec1, const unsigned char* hasMapPoint1,
+                               const FrameView& KF2, const MapT& featVec2, const unsigned char* hasMapPoint2, const float* F12,
+                               float ex, float ey, const float* levelSigma2_2, bool bOnlyStereo,
+                               std::vector<std::pair<size_t, size_t> >& vMatchedPairs) {
+        std::vector<int> m12(KF1.N, -1);
+        const FlatFeatureVector a = Flatten(featVec1), b = Flatten(featVec2);
+        const orbm_feature_vector ca = a.c(), cb = b.c();
+        orbm_frame f1 = KF1.c(), f2 = KF2.c();
+        int n = 0;
+        orbx::check(orbm_search_for_triangulation(m_, &f1, &ca, hasMapPoint1, KF1.uRight, &f2, &cb, hasMapPoint2, KF2.uRight, F12,
+                                                  ex, ey, KF2.scaleFactors, levelSigma2_2, KF2.nLevels, bOnlyStereo,
+                                                  mbCheckOrientation, m12.data(), &n, ORBX_MEM_HOST),
+                    "orbm_search_for_triangulation");
+        vMatchedPairs.clear();
+        for (size_t i = 0; i < m12.size(); i++)
+            if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
+        return n;
+    }
+
+    // Candidate loop of Fuse and SearchBySim3 (reference src/ORBmatcher.cc:1066-1120, :1391-1416):
+    // bestIdx / bestDist per projected map point; the caller applies TH_LOW / TH_HIGH and the
+    // map point bookkeeping of :1123-1148.
+    void WindowBest(const FrameView& KF, int n, const unsigned char* valid, const float* u, const float* v, const float* radius,
+                    const int* level, const unsigned char* mpDesc, bool chi2Gate, const float* qURight,
+                    const float* invLevelSigma2, std::vector<int>& bestIdx, std::vector<int>& bestDist) {
+        bestIdx.assign(n, -1);
+        bestDist.assign(n, 256);
+        if (n == 0) return;
+        orbm_frame f = KF.c();
+        orbx::check(orbm_window_best(m_, &f, n, valid, u, v, radius, level, mpDesc, chi2Gate, KF.uRight, qURight, invLevelSigma2,
+                                     KF.nLevels, bestIdx.data(), bestDist.data(), ORBX_MEM_HOST),
+                    "orbm_window_best");
+    }
+
+    // MapPoint::ComputeDistinctiveDescriptors for many map points (reference src/MapPoint.cc:279-341).
+    void ComputeDistinctiveDescriptors(const unsigned char* descriptors, const std::vector<int>& groupStart,
+                                       std::vector<int>& bestIdx, std::vector<unsigned char>& chosen) {
+        const int g = (int)groupStart.size() - 1;
+        bestIdx.assign(g > 0 ? g : 0, -1);
+        chosen.assign((size_t)(g > 0 ? g : 0) * 32, 0);
+        if (g <= 0) return;
+        orbx::check(orbm_distinctive_descriptors(m_, descriptors, groupStart.data(), g, bestIdx.data(), nullptr, chosen.data(),
+                                                 groupStart.back(), ORBX_MEM_HOST),
+                    "orbm_distinctive_descriptors");
     }
 
     orbm_context* context() { return m_; }

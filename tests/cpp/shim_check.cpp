@@ -7,6 +7,7 @@
 // (reference src/Frame.cc:603) and appends mvuRight and mvDepth to the output.
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <vector>
 
 #include "../../include/orbx_shim.hpp"
@@ -51,6 +52,21 @@ int main(int argc, char** argv) {
             std::fwrite(&ns, 4, 1, o);
             std::fwrite(uRight.data(), 4, uRight.size(), o);
             std::fwrite(depth.data(), 4, depth.size(), o);
+            // SearchByBoW the way Tracking::TrackReferenceKeyFrame calls it (reference src/Tracking.cc:1166),
+            // with a stand-in vocabulary: node = keypoint row band of 16 px
+            std::map<unsigned, std::vector<unsigned> > fvL, fvR;
+            for (size_t i = 0; i < keys.size(); i++) fvL[(unsigned)(keys[i].y / 16)].push_back((unsigned)i);
+            for (size_t i = 0; i < keysRight.size(); i++) fvR[(unsigned)(keysRight[i].y / 16)].push_back((unsigned)i);
+            const std::vector<float> sf = extractor.GetScaleFactors();
+            ORB_SLAM2::FrameView vl = {keys.data(), desc.data(), n, 0, 0, (float)w, (float)h, sf.data(), 8, uRight.data()};
+            ORB_SLAM2::FrameView vr = {keysRight.data(), descRight.data(), (int)keysRight.size(), 0, 0, (float)w, (float)h,
+                                       sf.data(), 8, nullptr};
+            std::vector<unsigned char> all(n, 1);
+            std::vector<int> m12, m21;
+            ORB_SLAM2::ORBmatcher bow(0.7f, true);
+            int nb = bow.SearchByBoW(vl, fvL, all.data(), vr, fvR, nullptr, false, m12, m21);
+            std::fwrite(&nb, 4, 1, o);
+            std::fwrite(m12.data(), 4, m12.size(), o);
         }
         std::fclose(o);
         std::printf("%d keypoints\n", n);

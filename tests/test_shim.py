@@ -72,6 +72,22 @@ def test_shim_stereo_matches_ctypes(tmp_path):
     ur2, dp2, ns2 = m.ComputeStereoMatches(el, er, kl, dl, kr, dr, 0.54, 386.1448)
     assert n == len(kl) and ns == ns2 and ns > 100
     assert np.array_equal(ur.view(np.uint32), ur2.view(np.uint32)) and np.array_equal(dp.view(np.uint32), dp2.view(np.uint32))
+    # SearchByBoW through the shim against the ctypes path, same stand-in vocabulary
+    from slam_amd.matcher import FrameView
+    rest = tail[4 + 8 * n:]
+    nb = int(np.frombuffer(rest[:4], np.int32)[0])
+    m12 = np.frombuffer(rest[4:4 + 4 * n], np.int32)
+    fvl, fvr = {}, {}
+    for i, y in enumerate(kl["y"]):
+        fvl.setdefault(int(np.float32(y) / np.float32(16)), []).append(i)
+    for i, y in enumerate(kr["y"]):
+        fvr.setdefault(int(np.float32(y) / np.float32(16)), []).append(i)
+    sf = el.GetScaleFactors()
+    mb = ORBmatcher(0.7, True)
+    nb2, m12b, _ = mb.SearchByBoW(FrameView(kl, dl, (0, 0, 640, 480), sf), fvl, np.ones(n, np.uint8),
+                                  FrameView(kr, dr, (0, 0, 640, 480), sf), fvr)
+    mb.close()
+    assert nb == nb2 and nb > 100 and np.array_equal(m12, m12b)
     m.close()
     el.close()
     er.close()
