@@ -107,7 +107,8 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int h_
 /* mvImagePyramid[level] of frame `frame` of the last extract call (public
  * member read by Frame::ComputeStereoMatches, reference src/Frame.cc:610,700).
  * *ptr is DEVICE memory owned by the handle (level 0 aliases the caller's
- * image when it was passed as device memory), valid until the next call. */
+ * image when it was passed as device memory), valid until the next call.  A batch longer
+ * than max_batch is processed in passes; only the frames of the last pass stay resident. */
 int orbx_get_level(orbx_handle* h, int frame, int level, const uint8_t** ptr, int* w, int* h_,
                    size_t* stride);
 
@@ -140,7 +141,8 @@ int orbx_profile_reset(orbx_handle* h);
  * sine/cosine (radians) and fastAtan2 (degrees), n values each, host arrays. */
 int orbx_debug_sincos(orbx_handle* h, const float* angles, int n, float* sin_out, float* cos_out);
 int orbx_debug_atan2(orbx_handle* h, const float* y, const float* x, int n, float* out);
-/* Pyramid level image of frame `frame`: copies w*h bytes, tightly packed, to host dst. */
+/* Pyramid level image of frame `frame` (index in the batch of the last call, as in
+ * orbx_get_level): copies w*h bytes, tightly packed, to host dst. */
 int orbx_debug_level(orbx_handle* h, int frame, int level, uint8_t* dst);
 /* Blurred level image of frame `frame`: copies w*h bytes, tightly packed, to host dst. */
 int orbx_debug_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, int* w, int* h_);

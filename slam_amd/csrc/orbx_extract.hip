@@ -30,6 +30,7 @@ typedef uint32_t u32;
 typedef unsigned long long u64;
 typedef long long i64;
 
+const int ORBX_PIPES = 3;
 const int EDGE_THRESHOLD = 19;  // reference src/ORBextractor.cc:53
 const int MIN_BORDER = EDGE_THRESHOLD - 3;
 const int MAX_CELL = 59;  // largest cell side: ceil(width / floor(width/30)) < 60
@@ -1337,10 +1338,24 @@ struct orbx_handle {
     // scratch sized for scratchBatch frames of the current geometry
     int scratchBatch = 0;
     size_t scratchSig = 0;
+    // d* are the blocks of the pass being enqueued (a view into the owned base* allocations:
+    // with several passes in flight each one works in its own slice)
     u8 *dPyr = nullptr, *dBlur = nullptr;
     u32 *dCellCount = nullptr, *dSlots = nullptr, *dKeyPacked = nullptr, *dSel = nullptr;
     u16* dKeyNode = nullptr;
     int *dSelCount = nullptr, *dErr = nullptr;
+    u8 *basePyr = nullptr, *baseBlur = nullptr;
+    u32 *baseCellCount = nullptr, *baseSlots = nullptr, *baseKeyPacked = nullptr, *baseSel = nullptr;
+    u16* baseKeyNode = nullptr;
+    int* baseSelCount = nullptr;
+    // Device-memory batches longer than one pass are spread over ORBX_PIPES passes in flight,
+    // each on its own pair of streams (pipe 0 = the handle's own), so that the tail of one pass
+    // and its latency-bound kernels run beside the next pass.
+    struct Pipe {
+        hipStream_t st = nullptr, aux = nullptr;
+        hipEvent_t evPyramid = nullptr, evBlur = nullptr, evDone = nullptr;
+    } pipes[ORBX_PIPES];
+    hipEvent_t evStart = nullptr;
     // staging for host-memory calls
     u8* dImgStage = nullptr;
     size_t imgStageCap = 0;
@@ -1683,25 +1698,50 @@ int ensure_scratch(orbx_handle* h, int batch) {
     const Geom& g = h->g;
     const size_t sig = (size_t)g.w * 73856093u ^ (size_t)g.h * 19349663u;
     if (h->scratchSig == sig && batch <= h->scratchBatch) return ORBX_OK;
-    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-    free_dev(h->dPyr); free_dev(h->dBlur); free_dev(h->dCellCount); free_dev(h->dSlots);
-    free_dev(h->dKeyPacked); free_dev(h->dKeyNode); free_dev(h->dSel); free_dev(h->dSelCount);
-    h->dPyr = h->dBlur = nullptr;
-    h->dCellCount = h->dSlots = h->dKeyPacked = h->dSel = nullptr;
-    h->dKeyNode = nullptr;
-    h->dSelCount = nullptr;
+    ORBX_HIP_CHECK(hipDeviceSynchronize());
+    free_dev(h->basePyr); free_dev(h->baseBlur); free_dev(h->baseCellCount); free_dev(h->baseSlots);
+    free_dev(h->baseKeyPacked); free_dev(h->baseKeyNode); free_dev(h->baseSel); free_dev(h->baseSelCount);
+    h->basePyr = h->baseBlur = nullptr;
+    h->baseCellCount = h->baseSlots = h->baseKeyPacked = h->baseSel = nullptr;
+    h->baseKeyNode = nullptr;
+    h->baseSelCount = nullptr;
     h->scratchBatch = 0;
     const size_t B = (size_t)batch;
-    ORBX_HIP_CHECK(hipMalloc((void**)&h->dPyr, B * g.pyrFrameBytes + 256));
-    ORBX_HIP_CHECK(hipMalloc((void**)&h->dBlur, B * g.blurFrameBytes + 256));
-    ORBX_HIP_CHECK(hipMalloc((void**)&h->dCellCount, B * g.totalCells * sizeof(u32)));
-    ORBX_HIP_CHECK(hipMalloc((void**)&h->dSlots, B * g.totalSlots * sizeof(u32)));
-    ORBX_HIP_CHECK(hipMalloc((void**)&h->dKeyPacked, B * g.totalSlots * sizeof(u32)));
-    ORBX_HIP_CHECK(hipMalloc((void**)&h->dKeyNode, B * g.totalSlots * sizeof(u16)));
-    ORBX_HIP_CHECK(hipMalloc((void**)&h->dSel, B * g.totalSel * sizeof(u32)));
-    ORBX_HIP_CHECK(hipMalloc((void**)&h->dSelCount, B * ORBX_MAX_LEVELS * sizeof(int)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->basePyr, B * g.pyrFrameBytes + 256));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->baseBlur, B * g.blurFrameBytes + 256));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->baseCellCount, B * g.totalCells * sizeof(u32)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->baseSlots, B * g.totalSlots * sizeof(u32)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->baseKeyPacked, B * g.totalSlots * sizeof(u32)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->baseKeyNode, B * g.totalSlots * sizeof(u16)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->baseSel, B * g.totalSel * sizeof(u32)));
+    ORBX_HIP_CHECK(hipMalloc((void**)&h->baseSelCount, B * ORBX_MAX_LEVELS * sizeof(int)));
     h->scratchBatch = batch;
     h->scratchSig = sig;
+    return ORBX_OK;
+}
+
+// Points the d* views at the slice that starts `frame0` frames into the scratch.
+void select_scratch(orbx_handle* h, size_t frame0) {
+    const Geom& g = h->g;
+    h->dPyr = h->basePyr + frame0 * g.pyrFrameBytes;
+    h->dBlur = h->baseBlur + frame0 * g.blurFrameBytes;
+    h->dCellCount = h->baseCellCount + frame0 * g.totalCells;
+    h->dSlots = h->baseSlots + frame0 * g.totalSlots;
+    h->dKeyPacked = h->baseKeyPacked + frame0 * g.totalSlots;
+    h->dKeyNode = h->baseKeyNode + frame0 * g.totalSlots;
+    h->dSel = h->baseSel + frame0 * g.totalSel;
+    h->dSelCount = h->baseSelCount + frame0 * ORBX_MAX_LEVELS;
+}
+
+// Streams and events of pipe p >= 1, created on first use.
+int ensure_pipe(orbx_handle* h, int p) {
+    orbx_handle::Pipe& P = h->pipes[p];
+    if (P.st) return ORBX_OK;
+    ORBX_HIP_CHECK(hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking));
+    ORBX_HIP_CHECK(hipStreamCreateWithFlags(&P.aux, hipStreamNonBlocking));
+    ORBX_HIP_CHECK(hipEventCreateWithFlags(&P.evPyramid, hipEventDisableTiming));
+    ORBX_HIP_CHECK(hipEventCreateWithFlags(&P.evBlur, hipEventDisableTiming));
+    ORBX_HIP_CHECK(hipEventCreateWithFlags(&P.evDone, hipEventDisableTiming));
     return ORBX_OK;
 }
 
@@ -1889,8 +1929,18 @@ void orbx_destroy(orbx_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    free_dev(h->dPyr); free_dev(h->dBlur); free_dev(h->dCellCount); free_dev(h->dSlots);
-    free_dev(h->dKeyPacked); free_dev(h->dKeyNode); free_dev(h->dSel); free_dev(h->dSelCount);
+    (void)hipDeviceSynchronize();
+    free_dev(h->basePyr); free_dev(h->baseBlur); free_dev(h->baseCellCount); free_dev(h->baseSlots);
+    free_dev(h->baseKeyPacked); free_dev(h->baseKeyNode); free_dev(h->baseSel); free_dev(h->baseSelCount);
+    for (int p = 1; p < ORBX_PIPES; p++) {
+        orbx_handle::Pipe& P = h->pipes[p];
+        if (P.st) (void)hipStreamDestroy(P.st);
+        if (P.aux) (void)hipStreamDestroy(P.aux);
+        if (P.evPyramid) (void)hipEventDestroy(P.evPyramid);
+        if (P.evBlur) (void)hipEventDestroy(P.evBlur);
+        if (P.evDone) (void)hipEventDestroy(P.evDone);
+    }
+    if (h->evStart) (void)hipEventDestroy(h->evStart);
     free_dev(h->dErr); free_dev(h->dTaps); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dKpStage);
     free_dev(h->dDescStage); free_dev(h->dNStage);
     for (int s = 0; s < ORBX_STAGE_COUNT; s++)
@@ -1965,9 +2015,22 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
     int rc = compute_geometry(h, w, hh);
     if (rc) return rc;
     const int chunk = std::min(B, h->cfg.max_batch);
-    rc = ensure_scratch(h, chunk);
+    const int npass = (B + chunk - 1) / chunk;
+    const int npipes = (mem_space == ORBX_MEM_DEVICE && h->overlapBlur) ? std::min(ORBX_PIPES, npass) : 1;
+    rc = ensure_scratch(h, chunk * npipes);
     if (rc) return rc;
+    select_scratch(h, 0);
     const int cap = cap_per_frame;
+    hipStream_t mainStream = h->stream, mainAux = h->auxStream;
+    hipEvent_t mainEvPyr = h->evPyramid, mainEvBlur = h->evBlur;
+    if (npipes > 1) {
+        if (!h->evStart) ORBX_HIP_CHECK(hipEventCreateWithFlags(&h->evStart, hipEventDisableTiming));
+        ORBX_HIP_CHECK(hipEventRecord(h->evStart, mainStream));
+        for (int p = 1; p < npipes; p++) {
+            if ((rc = ensure_pipe(h, p))) return rc;
+            ORBX_HIP_CHECK(hipStreamWaitEvent(h->pipes[p].st, h->evStart, 0));
+        }
+    }
     if (mem_space == ORBX_MEM_HOST) {
         const size_t imgBytes = (size_t)chunk * w * hh;
         if (imgBytes > h->imgStageCap) {
@@ -2021,12 +2084,29 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
             img0.base = imgs + (size_t)f0 * img_stride;
             img0.pitch = (int)row_stride;
             img0.frameStride = (i64)img_stride;
+            const int p = (f0 / chunk) % npipes;
+            if (p > 0) {
+                h->stream = h->pipes[p].st;
+                h->auxStream = h->pipes[p].aux;
+                h->evPyramid = h->pipes[p].evPyramid;
+                h->evBlur = h->pipes[p].evBlur;
+            }
+            select_scratch(h, (size_t)p * chunk);
             rc = run_pass(h, img0, n, kps + (size_t)f0 * cap, desc + (size_t)f0 * cap * 32, cap, n_out + f0);
+            h->stream = mainStream;
+            h->auxStream = mainAux;
+            h->evPyramid = mainEvPyr;
+            h->evBlur = mainEvBlur;
             if (rc) return rc;
         }
         h->lastImg0 = img0;
         h->lastBatch = n;
         h->lastFirstFrame = f0;
+    }
+    // the handle's stream continues when every pipe has finished its passes
+    for (int p = 1; p < npipes; p++) {
+        ORBX_HIP_CHECK(hipEventRecord(h->pipes[p].evDone, h->pipes[p].st));
+        ORBX_HIP_CHECK(hipStreamWaitEvent(mainStream, h->pipes[p].evDone, 0));
     }
     return ORBX_OK;
 }
@@ -2143,7 +2223,7 @@ int orbx_debug_level(orbx_handle* h, int frame, int level, uint8_t* dst) {
     const uint8_t* ptr = nullptr;
     int w = 0, hh = 0;
     size_t stride = 0;
-    int rc = orbx_get_level(h, frame + (h ? h->lastFirstFrame : 0), level, &ptr, &w, &hh, &stride);
+    int rc = orbx_get_level(h, frame, level, &ptr, &w, &hh, &stride);
     if (rc) return rc;
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     ORBX_HIP_CHECK(hipMemcpy2D(dst, w, ptr, stride, w, hh, hipMemcpyDeviceToHost));

@@ -235,3 +235,41 @@ def test_large_batch_properties(extractor_vga):
         assert 1000 <= n[f] <= cap
         assert (np.diff(k["octave"]) >= 0).all() and (k["class_id"] == -1).all()
         assert (k["angle"] >= 0).all() and (k["angle"] <= 360).all()
+
+
+def test_passes_in_flight_equal_single_frames(oracle):
+    """A device-resident batch longer than one pass is spread over several passes in flight
+    (own streams, own scratch slices); the result must equal frame-by-frame extraction, with
+    the overlap on and off, and repeated calls must not disturb each other."""
+    import torch
+    from slam_amd._lib import KP_DTYPE
+    from slam_amd.extractor import ORBextractor
+    B, chunk = 44, 8   # 6 passes: 5 full + 1 of 4 frames, over 3 pipes
+    frames = synth.synth_batch_torch(B, 640, 480, 7100, device="cuda")
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=chunk)
+    one = ORBextractor(1000, 1.2, 8, 20, 7)
+    try:
+        cap = ex.max_keypoints()
+        host = frames.cpu().numpy()
+        want = [one(host[f], None) for f in (0, 7, 8, 23, 40, 43)]
+        for overlap in (True, False, True):
+            ex.set_overlap(overlap)
+            d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+            d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+            d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ex.extract_batch_device(frames, d_kps, d_desc, d_n, cap)
+            ex.extract_batch_device(frames, d_kps, d_desc, d_n, cap)   # back to back on the same buffers
+            ex.synchronize()
+            n = d_n.cpu().numpy()
+            kps = d_kps.cpu().numpy().view(KP_DTYPE).reshape(B, cap)
+            desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+            for (k, d), f in zip(want, (0, 7, 8, 23, 40, 43)):
+                assert n[f] == len(k)
+                assert kps[f, :n[f]].tobytes() == k.tobytes() and np.array_equal(desc[f, :n[f]], d)
+        # the pyramid of the last pass stays addressable (frames 40..43)
+        lvl = ex.image_pyramid_level(41, 3)
+        assert np.array_equal(lvl, oracle.pyramid_level(oracle.params(), host[41], 3))
+    finally:
+        ex.close()
+        one.close()
