@@ -701,16 +701,22 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-// Exclusive scan over the 256 threads of the block; *total = block sum.
+#define QT_THREADS 256  // measured on MI355X: 128 and 512 threads are slower, a single wave much slower
+
+// Exclusive scan over the QT_THREADS threads of the block; *total = block sum.
 __device__ __forceinline__ int block_excl_scan(int v, int* total, int* wsum) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int inc = wave_incl_scan(v);
+    if (QT_THREADS == 64) {
+        *total = __builtin_amdgcn_readlane(inc, 63);
+        return inc - v;
+    }
     __syncthreads();
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < QT_THREADS / 64; k++) {
         const int s = wsum[k];
         if (k < wv) base += s;
         tot += s;
@@ -721,7 +727,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* wsum) {
 
 struct QtShared {
     int n, L, prevL, tnew, ncut, nproc, toExpand, done, careful, C;
-    int wsum[4];
+    int wsum[16];
 };
 
 __device__ __forceinline__ int child_quadrant(u32 key, short4 b) {
@@ -748,7 +754,7 @@ __device__ __forceinline__ short4 child_box(short4 b, int q) {
 // sums so that positions, creation order and the stop rule equal those of the
 // sequential algorithm.  Node "addresses" in the size sort are modelled by
 // creation order (later created = greater).
-__global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict__ cellCount,
+__global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __restrict__ cellCount,
                                                    const u32* __restrict__ slots, u32* keyPacked,
                                                    u16* keyNode, u32* sel, int* selCount,
                                                    int* errFlag) {
@@ -788,7 +794,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
     u32* kp = keyPacked + (i64)f * g.totalSlots + LG.slotBase;
     u16* kn = keyNode + (i64)f * g.totalSlots + LG.slotBase;
     int nkeys = 0;
-    for (int base = 0; base < LG.nCells; base += 256) {
+    for (int base = 0; base < LG.nCells; base += QT_THREADS) {
         const int c = base + tid;
         const int cN = c < LG.nCells ? (int)cc[c] : 0;
         int tot;
@@ -806,9 +812,9 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
     const int nIni = LG.nIni;
     const float hX = LG.hX;
     const int ySpan = LG.h - 2 * MIN_BORDER;
-    for (int i = tid; i < lcap; i += 256) cnt[0][i] = 0;
+    for (int i = tid; i < lcap; i += QT_THREADS) cnt[0][i] = 0;
     __syncthreads();
-    for (int k = tid; k < nkeys; k += 256) {
+    for (int k = tid; k < nkeys; k += QT_THREADS) {
         const int r = (int)((float)ORBX_PX(kp[k]) / hX);
         kn[k] = (u16)r;
         atomicAdd(&cnt[0][r], 1u);
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
         S.done = 0;
     }
     __syncthreads();
-    for (int k = tid; k < nkeys; k += 256) kn[k] = moved[kn[k]];
+    for (int k = tid; k < nkeys; k += QT_THREADS) kn[k] = moved[kn[k]];
     int cur = 1;  // buffer holding the current list
     u32 nextSeq = (u32)nIni;
     __syncthreads();
@@ -850,9 +856,9 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
         const u32* ccnt = cnt[cur];
         const u32* cseq = seq[cur];
         const int nxt = cur ^ 1;
-        for (int i = tid; i < L * 4; i += 256) childCnt[i] = 0;
+        for (int i = tid; i < L * 4; i += QT_THREADS) childCnt[i] = 0;
         __syncthreads();
-        for (int k = tid; k < nkeys; k += 256) {
+        for (int k = tid; k < nkeys; k += QT_THREADS) {
             const int nd = kn[k];
             if (ccnt[nd] > 1) atomicAdd(&childCnt[nd * 4 + child_quadrant(kp[k], cb[nd])], 1u);
         }
@@ -860,7 +866,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
         // processing order of expandable nodes
         int C = 0;
         if (!careful) {
-            for (int base = 0; base < L; base += 256) {
+            for (int base = 0; base < L; base += QT_THREADS) {
                 const int i = base + tid;
                 const int e = (i < L && ccnt[i] > 1) ? 1 : 0;
                 int tot;
@@ -870,7 +876,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
             }
         } else {
             // rank by (count desc, creation order desc)
-            for (int i = tid; i < L; i += 256) {
+            for (int i = tid; i < L; i += QT_THREADS) {
                 const u32 ci = ccnt[i];
                 u16 r = 0xFFFF;
                 if (ci > 1) {
@@ -884,7 +890,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
                 }
                 rankOf[i] = r;
             }
-            for (int base = 0; base < L; base += 256) {
+            for (int base = 0; base < L; base += QT_THREADS) {
                 const int i = base + tid;
                 const int e = (i < L && ccnt[i] > 1) ? 1 : 0;
                 int tot;
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
             }
         }
         __syncthreads();
-        for (int i = tid; i < L; i += 256) {
+        for (int i = tid; i < L; i += QT_THREADS) {
             const u16 r = rankOf[i];
             int m = 0;
             if (r != 0xFFFF) {
@@ -906,7 +912,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
         __syncthreads();
         // scan over ranks: children created before rank j, and the cut
         int run = 0, below = 0;
-        for (int base = 0; base < C; base += 256) {
+        for (int base = 0; base < C; base += QT_THREADS) {
             const int j = base + tid;
             const int m = j < C ? (int)mOf[nodeOfRank[j]] : 0;
             int tot;
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
         }
         // nodes that stay: new position = tnew + rank among stayers in list order
         int stay = 0;
-        for (int base = 0; base < L; base += 256) {
+        for (int base = 0; base < L; base += QT_THREADS) {
             const int i = base + tid;
             const int s = (i < L && (rankOf[i] == 0xFFFF || rankOf[i] >= nproc)) ? 1 : 0;
             int tot;
@@ -950,7 +956,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
         }
         // children of processed nodes, pushed to the front in processing order
         int expand = 0;
-        for (int i = tid; i < L; i += 256) {
+        for (int i = tid; i < L; i += QT_THREADS) {
             const u16 r = rankOf[i];
             if (r != 0xFFFF && r < nproc) {
                 int gidx = (int)gpre[r];
@@ -976,7 +982,7 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
             expand = tot;
         }
         __syncthreads();
-        for (int k = tid; k < nkeys; k += 256) {
+        for (int k = tid; k < nkeys; k += QT_THREADS) {
             const int nd = kn[k];
             const u16 r = rankOf[nd];
             if (r != 0xFFFF && r < nproc)
@@ -1006,14 +1012,14 @@ __global__ __launch_bounds__(256) void k_quadtree(Geom g, const u32* __restrict_
     // ---- best key per node: max response, first in candidate order on ties
     const int L = S.L;
     u64* best = (u64*)childCnt;
-    for (int i = tid; i < L; i += 256) best[i] = 0;
+    for (int i = tid; i < L; i += QT_THREADS) best[i] = 0;
     __syncthreads();
-    for (int k = tid; k < nkeys; k += 256) {
+    for (int k = tid; k < nkeys; k += QT_THREADS) {
         const u64 v = ((u64)ORBX_PR(kp[k]) << 32) | (u64)(0xFFFFFFFFu - (u32)k);
         atomicMax(&best[kn[k]], v);
     }
     __syncthreads();
-    for (int i = tid; i < L; i += 256) {
+    for (int i = tid; i < L; i += QT_THREADS) {
         const u32 k = 0xFFFFFFFFu - (u32)(best[i] & 0xFFFFFFFFu);
         const u32 key = kp[k];
         selOut[i] = ORBX_PACK(ORBX_PX(key) + MIN_BORDER, ORBX_PY(key) + MIN_BORDER, ORBX_PR(key));
@@ -1841,7 +1847,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     }
     {
         StageTimer t(h, ORBX_STAGE_QUADTREE);
-        dim3 grid(g.nlevels, n, 1), block(256, 1, 1);
+        dim3 grid(g.nlevels, n, 1), block(QT_THREADS, 1, 1);
         hipLaunchKernelGGL(k_quadtree, grid, block, h->qtLds, st, g, (const u32*)h->dCellCount,
                            (const u32*)h->dSlots, h->dKeyPacked, h->dKeyNode, h->dSel, h->dSelCount, h->dErr);
     }
