@@ -1305,13 +1305,33 @@ __global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int n
         }
     };
     int j = 0;
-    // four train rows per trip: their scalar loads are issued together, ahead of the math
+    // Four train rows per trip: their scalar loads are issued together, ahead of the math.  The
+    // top-2 update is skipped for a trip unless some lane of the wave met a distance that can
+    // enter its top 2 (distance <= current second-best distance), which soon becomes rare.
     for (; j + 4 <= nt; j += 4) {
         uint4 b[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) b[r] = t[(i64)j * 2 + r];
+        u32 d[KNN_QPT][4];
+        bool any = false;
 #pragma unroll
-        for (int r = 0; r < 4; r++) visit(b[2 * r], b[2 * r + 1], j + r);
+        for (int k = 0; k < KNN_QPT; k++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) d[k][r] = (u32)hamming256(qa[k][0], qa[k][1], b[2 * r], b[2 * r + 1]);
+            const u32 m = min(min(d[k][0], d[k][1]), min(d[k][2], d[k][3]));
+            any |= m <= (second[k] >> KNN_IDX_BITS);
+        }
+        if (__any(any)) {
+#pragma unroll
+            for (int k = 0; k < KNN_QPT; k++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const u32 key = (d[k][r] << KNN_IDX_BITS) | (u32)(j + r);
+                    second[k] = umed3(best[k], second[k], key);
+                    best[k] = min(best[k], key);
+                }
+            }
+        }
     }
     for (; j < nt; j++) visit(t[(i64)j * 2], t[(i64)j * 2 + 1], j);
 #pragma unroll
