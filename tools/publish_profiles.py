@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Copies the condensed rocprofv3 results of tools/collect_profiles.sh (gpurun_out/prof_<tag>/)
+into profiles/: <tag>_kernel_stats.csv, <tag>_summary.json, <tag>_rocprofv3_kernel_stats_full.csv
+and pmc_traffic.json (HBM bytes per launch by stage, the file bench.py reads)."""
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = os.path.join("gpurun_out", "prof_" + tag)
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(os.path.join(src, "kernel_stats_%s.csv" % tag), os.path.join("profiles", "%s_kernel_stats.csv" % tag))
+shutil.copy(os.path.join(src, "summary_%s.json" % tag), os.path.join("profiles", "%s_summary.json" % tag))
+full = os.path.join(src, "stats", "s_kernel_stats.csv")
+if os.path.exists(full):
+    shutil.copy(full, os.path.join("profiles", "%s_rocprofv3_kernel_stats_full.csv" % tag))
+summ = json.load(open(os.path.join(src, "summary_%s.json" % tag)))
+stage_of = {"k_fast": "fast", "k_quadtree": "quadtree", "k_blur_stream": "blur", "k_describe": "describe",
+            "k_resize_stream": "pyramid"}
+out = {}
+for k, t in summ["traffic"].items():
+    if k not in stage_of:
+        continue
+    mult = 7 if k == "k_resize_stream" else 1   # seven levels per pass
+    out[stage_of[k]] = {"kernel": k + (" (7 launches, summed)" if mult > 1 else ""),
+                        "hbm_bytes_per_launch": t["hbm_bytes_per_launch"] * mult,
+                        "frames_per_launch": t["frames_per_launch"],
+                        "read_bytes_corrected": t["read_bytes_corrected"] * mult,
+                        "write_bytes": t["write_bytes"] * mult}
+json.dump(out, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
