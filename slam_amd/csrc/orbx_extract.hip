@@ -509,6 +509,18 @@ __device__ __forceinline__ u32 pair_test2(u32 v, u32 u, u32 d, u32 l, u32 r, u32
     return (as_u32(t1) | as_u32(t2)) & 0x80008000u;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP adds: Hillis-Steele inside each row of 16
+// lanes, then the row totals handed on with the two row broadcasts.
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // One wave per cell.  ROI -> LDS (aligned 32-bit loads), then a cascade:
 //   1. the pair test above on 4 pixels per lane (one LDS word and its four neighbour
 //      words); survivors queued in raster order as (y << 8 | x),
@@ -576,7 +588,16 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
 
     u32* out = slots + (i64)f * g.totalSlots + C.w[2];
     const int gx0 = C.w[4] & 0xffff, gy0 = C.w[4] >> 16;  // relative to the detection origin
-    const int items = ih * nk;
+    // Pair test: a lane owns word kk of row lr inside a group of rowsPer rows and moves down the
+    // interior one group per step, so its addresses advance by a constant and its mask of
+    // pixels that lie inside the interior is fixed.
+    const int rowsPer = 64 / nk;
+    const int lr = (int)fastdiv((u32)lane, (u32)nk, mgk), kk = lane - lr * nk;
+    const bool laneOn = lr < rowsPer;
+    const int xb0 = 4 * (k0 + kk) - X0;  // interior x of the word's first pixel
+    const u32 vmask = (15u << max(-xb0, 0)) & (15u >> (4 - min(max(iw - xb0, 0), 4)));
+    const u8* rcBase = roi + (lr + 3) * RP + 4 * (k0 + kk);
+    const int entBase = (lr << 8) + xb0;
     int total = 0;
     for (int pass = 0; pass < 2; pass++) {
         const int th = min(max(pass == 0 ? iniTh : minTh, 0), 255);
@@ -586,36 +607,26 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
             __syncthreads();
         }
         int n1 = 0;
-        for (int base = 0; base < items; base += 64) {
-            const int it = base + lane;
+        for (int yb = 0; yb < ih; yb += rowsPer) {
             u32 m4 = 0;
-            int y = 0, xb = 0;
-            if (it < items) {
-                y = fastdiv(it, nk, mgk);
-                const int k = k0 + (it - y * nk);
-                const u32* rc = (const u32*)(roi + (y + 3) * RP) + k;
+            if (laneOn && yb + lr < ih) {
+                const u32* rc = (const u32*)(rcBase + yb * RP);
                 const u32 Cw = rc[0], Lw = rc[-1], Rw = rc[1];
-                const u32 Uw = ((const u32*)(roi + y * RP))[k], Dw = ((const u32*)(roi + (y + 6) * RP))[k];
+                const u32 Uw = *(const u32*)((const u8*)rc - 3 * RP), Dw = *(const u32*)((const u8*)rc + 3 * RP);
                 const u32 Rt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);  // pixels x + 3
                 const u32 Lf = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels x - 3
                 const u32 M = 0x00FF00FFu;
                 const u32 e = pair_test2(Cw & M, Uw & M, Dw & M, Lf & M, Rt & M, th2);
                 const u32 o = pair_test2(odd_bytes(Cw), odd_bytes(Uw), odd_bytes(Dw), odd_bytes(Lf), odd_bytes(Rt), th2);
                 const u32 mm = (e >> 1) | o;  // bits 14, 15, 30, 31 = pixels 0, 1, 2, 3 of the word
-                m4 = ((mm >> 14) & 3u) | ((mm >> 28) & 12u);
-                xb = 4 * k - X0;  // interior x of the word's first pixel
-                const int lo = max(-xb, 0), hi = min(iw - xb, 4);
-                m4 &= (15u << lo) & (15u >> (4 - hi));
+                m4 = (((mm >> 14) & 3u) | ((mm >> 28) & 12u)) & vmask;
             }
             // ordered compaction: lanes are in raster order and so are the pixels of a word
             const int c = __popc(m4);
-            const u64 b0 = __ballot(c & 1), b1 = __ballot(c & 2), b2 = __ballot(c & 4);
-            const int pre = __builtin_amdgcn_mbcnt_hi((u32)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b0, 0)) +
-                            2 * __builtin_amdgcn_mbcnt_hi((u32)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b1, 0)) +
-                            4 * __builtin_amdgcn_mbcnt_hi((u32)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b2, 0));
-            const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-            const int ent = (y << 8) + xb;  // + pixel index in the word = (y << 8 | x) for valid pixels
-            u16* qp = queue + n1 + pre;
+            const int inc = wave_incl_scan_dpp(c);
+            const int tot = __builtin_amdgcn_readlane(inc, 63);
+            const int ent = entBase + (yb << 8);  // + pixel index in the word = (y << 8 | x) for valid pixels
+            u16* qp = queue + n1 + inc - c;
             if (m4 & 1u) *qp++ = (u16)ent;
             if (m4 & 2u) *qp++ = (u16)(ent + 1);
             if (m4 & 4u) *qp++ = (u16)(ent + 2);
