@@ -483,9 +483,9 @@ __device__ __forceinline__ u32 div_magic(u32 d) { return d <= 1 ? 0u : (u32)(0x1
 // Per-cell constants, computed on the host when the geometry is set up so that a wave
 // starts without divisions or level searches.
 //   w0 = level | roi width << 8 | roi height << 16      w1 = iniX | iniY << 16
-//   w2 = slot offset inside the frame's slot block        w3 = slot capacity | nk << 16
+//   w2 = slot offset inside the frame's slot block        w3 = slot capacity | nk << 16 | (64 / nk) << 24
 //   w4 = gx0 | gy0 << 16 (detection-origin coordinates of the first interior pixel)
-//   w5 = magic(nW)   w6 = magic(nk)   w7 = nW
+//   w5 = magic(nW)   w6 = magic(nk)   w7 = nW | (64 / nW) << 8
 // nW = 32-bit words per ROI row when rows are fetched from a 4-byte aligned address,
 // nk = words per row that hold interior pixels in that layout.
 struct FastCell {
@@ -556,23 +556,33 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
     const int RP = g.fastRoiPitch;
     const ImgRef im = level_image(g, l, img0, pyr);
     const int iw = rw - 6, ih = rh - 6, pw = iw + 2;
-    int xo = 0, nk;
+    int xo = 0, nk, rowsPer;
     u32 mgk;
     if (l > 0 || img0Aligned) {
         const int xa = iniX & ~3;
         xo = iniX - xa;
-        const int nW = (int)C.w[7];
+        const int nW = (int)(C.w[7] & 255), rowsW = (int)((C.w[7] >> 8) & 255);
         const u32 mg = C.w[5];
-        nk = (int)(C.w[3] >> 16);
+        nk = (int)((C.w[3] >> 16) & 255);
+        rowsPer = (int)(C.w[3] >> 24);
         mgk = C.w[6];
-        const u8* srow = im.base + (i64)f * im.frameStride + (i64)iniY * im.pitch + xa;
-        for (int i = lane; i < nW * rh; i += 64) {
-            const int y = fastdiv(i, nW, mg), wd = i - y * nW;
-            ((u32*)(roi + y * RP))[wd] = *(const u32*)(srow + mul24((u32)y, (u32)im.pitch) + 4 * wd);
+        // a lane copies word wd of row lw inside a group of rowsW rows, group after group
+        const int lw = (int)fastdiv((u32)lane, (u32)nW, mg), wd = lane - lw * nW;
+        if (lw < rowsW) {
+            const u8* sp = im.base + (i64)f * im.frameStride + (i64)(iniY + lw) * im.pitch + xa + 4 * wd;
+            u8* dp = roi + lw * RP + 4 * wd;
+            const int sStep = rowsW * im.pitch, dStep = rowsW * RP;
+#pragma unroll 4
+            for (int y = lw; y < rh; y += rowsW) {
+                *(u32*)dp = *(const u32*)sp;
+                sp += sStep;
+                dp += dStep;
+            }
         }
     } else {
         const u32 mg = div_magic(rw);
         nk = ((3 + iw - 1) >> 2) + 1;
+        rowsPer = 64 / nk;
         mgk = div_magic(nk);
         const u8* srow = im.base + (i64)f * im.frameStride + (i64)iniY * im.pitch + iniX;
         for (int i = lane; i < rw * rh; i += 64) {
@@ -591,7 +601,6 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
     // Pair test: a lane owns word kk of row lr inside a group of rowsPer rows and moves down the
     // interior one group per step, so its addresses advance by a constant and its mask of
     // pixels that lie inside the interior is fixed.
-    const int rowsPer = 64 / nk;
     const int lr = (int)fastdiv((u32)lane, (u32)nk, mgk), kk = lane - lr * nk;
     const bool laneOn = lr < rowsPer;
     const int xb0 = 4 * (k0 + kk) - X0;  // interior x of the word's first pixel
@@ -1686,11 +1695,11 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
             F.w[0] = (u32)l | ((u32)rw << 8) | ((u32)rh << 16);
             F.w[1] = (u32)iniX | ((u32)iniY << 16);
             F.w[2] = (u32)(L.slotBase + c * L.cellCap);
-            F.w[3] = (u32)L.cellCap | ((u32)nk << 16);
+            F.w[3] = (u32)L.cellCap | ((u32)nk << 16) | ((u32)(64 / nk) << 24);
             F.w[4] = (u32)(cj * L.wCell + 3) | ((u32)(ci * L.hCell + 3) << 16);
             F.w[5] = magic(nW);
             F.w[6] = magic(nk);
-            F.w[7] = (u32)nW;
+            F.w[7] = (u32)nW | ((u32)(64 / std::max(nW, 1)) << 8);
             if (L.cellCap > 0xffff || rw > 255 || rh > 255) {
                 orbx_set_error("internal: cell record overflow");
                 return ORBX_ERR_UNSUPPORTED;
