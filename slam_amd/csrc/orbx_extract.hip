@@ -399,7 +399,13 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), W1, 0u, false), false);
         hs[3] = __builtin_amdgcn_udot4(Rw, W2, __builtin_amdgcn_udot4(Cw, W1, 0u, false), false);
     };
-    u32 win[7][4];
+    // Vertical pass on pairs of consecutive rows: P_r = (hs[r-1], hs[r]) as two 16-bit halves
+    // (row sums are < 2^16), so that output row y is four v_dot2_u32_u16:
+    //   P[y-2].(k0,k1) + P[y].(k2,k3) + P[y+2].(k2,k1) + P[y+3].(0,k0) + 32768.
+    // win[] is a ring of the last seven P (slot (ph + 6) % 7 receives P[y+3] at phase ph).
+    const u32 W01 = (u32)k0 | ((u32)k1 << 16), W23 = (u32)k2 | ((u32)k3 << 16), W21 = (u32)k2 | ((u32)k1 << 16),
+              W0h = (u32)k0 << 16;
+    u32 win[7][4], lastHs[4];
     Raw cur[7];
     {
         Raw ini[6];
@@ -407,8 +413,19 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
         for (int i = 0; i < 6; i++) ini[i] = fetch(y0 - 3 + i);
 #pragma unroll
         for (int i = 0; i < 7; i++) cur[i] = fetch(y0 + 3 + i);
+        u32 h0[4], h1[4];
+        hrow(ini[0], h0);
 #pragma unroll
-        for (int i = 0; i < 6; i++) hrow(ini[i], win[i]);
+        for (int i = 1; i < 6; i++) {
+            hrow(ini[i], h1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                win[i][k] = h0[k] | (h1[k] << 16);
+                h0[k] = h1[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) lastHs[k] = h0[k];
     }
     for (int yb = y0; yb < yEnd; yb += 7) {
         Raw nxt[7];
@@ -422,16 +439,19 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
 #pragma unroll
         for (int ph = 0; ph < 7; ph++) {
             const int y = yb + ph;
-            hrow(cur[ph], win[(ph + 6) % 7]);
-            // row sums are < 2^16 and pair sums < 2^17: 24-bit multiplies.  The rounded sum is
-            // < 2^25; clamped to 0xFFFFFF its byte 2 is the saturated output pixel.
+            u32 hs[4];
+            hrow(cur[ph], hs);
+            // The rounded sum is < 2^25; clamped to 0xFFFFFF its byte 2 is the saturated output pixel.
             u32 sv[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                u32 s = mad24((u32)k3, win[(ph + 3) % 7][k], 32768u);
-                s = mad24((u32)k2, win[(ph + 2) % 7][k] + win[(ph + 4) % 7][k], s);
-                s = mad24((u32)k1, win[(ph + 1) % 7][k] + win[(ph + 5) % 7][k], s);
-                s = mad24((u32)k0, win[ph % 7][k] + win[(ph + 6) % 7][k], s);
+                const u32 P3 = lastHs[k] | (hs[k] << 16);
+                win[(ph + 6) % 7][k] = P3;
+                lastHs[k] = hs[k];
+                u32 s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 1) % 7][k]), as_u16x2(W01), 32768u, false);
+                s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 3) % 7][k]), as_u16x2(W23), s, false);
+                s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 5) % 7][k]), as_u16x2(W21), s, false);
+                s = __builtin_amdgcn_udot2(as_u16x2(P3), as_u16x2(W0h), s, false);
                 sv[k] = min(s, 0xFFFFFFu);
             }
             const u32 lo = __builtin_amdgcn_perm(sv[1], sv[0], 0x0c0c0602u);  // bytes: sv0[2], sv1[2], 0, 0
