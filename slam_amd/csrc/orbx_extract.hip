@@ -1850,9 +1850,9 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     {
         StageTimer t(h, ORBX_STAGE_BLUR, bst);
         // Level 0 is the caller's buffer: the streaming kernel reads it as aligned 32-bit
-        // words, so it needs 4-byte aligned rows and a width that is a multiple of 4.
+        // words, so it needs 4-byte aligned rows that hold the last word of the row in full.
         const bool aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0 &&
-                              (g.w & 3) == 0 && img0.pitch >= g.w && g.h >= 4 && g.w >= 4;
+                              img0.pitch >= align_up(g.w, 4) && g.h >= 4 && g.w >= 4;
         const int first = aligned0 ? 0 : 1;
         if (!aligned0) {
             dim3 grid(g.lv[0].blurTiles, n, 1), block(256, 1, 1);
@@ -2078,7 +2078,7 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
         }
     }
     if (mem_space == ORBX_MEM_HOST) {
-        const size_t imgBytes = (size_t)chunk * w * hh;
+        const size_t imgBytes = (size_t)chunk * align_up(w, 64) * hh;
         if (imgBytes > h->imgStageCap) {
             ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
             free_dev(h->dImgStage);
@@ -2103,19 +2103,21 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
         const int n = std::min(chunk, B - f0);
         ImgRef img0;
         if (mem_space == ORBX_MEM_HOST) {
+            // staged rows are padded to 64 bytes so that every kernel can use aligned word loads
+            const size_t sp = (size_t)align_up(w, 64);
             if (img_stride == row_stride * (size_t)hh) {
-                ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage, (size_t)w, imgs + (size_t)f0 * img_stride, row_stride,
+                ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage, sp, imgs + (size_t)f0 * img_stride, row_stride,
                                                 (size_t)w, (size_t)hh * n, hipMemcpyHostToDevice, h->stream));
             } else {
                 // frames are not back to back in host memory: copy one by one
                 for (int f = 0; f < n; f++)
-                    ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage + (size_t)f * w * hh, (size_t)w,
+                    ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage + (size_t)f * sp * hh, sp,
                                                     imgs + (size_t)(f0 + f) * img_stride, row_stride, (size_t)w,
                                                     (size_t)hh, hipMemcpyHostToDevice, h->stream));
             }
             img0.base = h->dImgStage;
-            img0.pitch = w;
-            img0.frameStride = (i64)w * hh;
+            img0.pitch = (int)sp;
+            img0.frameStride = (i64)sp * hh;
             rc = run_pass(h, img0, n, h->dKpStage, h->dDescStage, cap, h->dNStage);
             if (rc) return rc;
             ORBX_HIP_CHECK(hipMemcpyAsync(kps + (size_t)f0 * cap, h->dKpStage, (size_t)n * cap * sizeof(orbx_keypoint),

@@ -273,3 +273,35 @@ def test_passes_in_flight_equal_single_frames(oracle):
     finally:
         ex.close()
         one.close()
+
+
+def test_width_not_multiple_of_four_device_resident(oracle):
+    """KITTI-sized frames (1241 px wide) in device memory with rows padded to 1244 bytes take the
+    aligned word paths; with a tight pitch of 1241 they take the byte paths.  Same result."""
+    import torch
+    from slam_amd._lib import KP_DTYPE
+    from slam_amd.extractor import ORBextractor
+    w, h, B = 1241, 376, 3
+    host = synth.synth_batch(B, w, h, 900)
+    ex = ORBextractor(2000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    try:
+        cap = ex.max_keypoints()
+        want = [oracle.extract(oracle.params(nfeatures=2000), host[f], cap=cap) for f in range(B)]
+        for pitch in (1244, 1241, 1280):
+            buf = torch.zeros((B, h, pitch), dtype=torch.uint8, device="cuda")
+            buf[:, :, :w] = torch.from_numpy(host).cuda()
+            d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+            d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+            d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ex.extract_batch_device(buf[:, :, :w], d_kps, d_desc, d_n, cap)
+            ex.synchronize()
+            n = d_n.cpu().numpy()
+            kps = d_kps.cpu().numpy().view(KP_DTYPE).reshape(B, cap)
+            desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+            for f in range(B):
+                k, d = want[f]
+                assert n[f] == len(k), pitch
+                assert kps[f, :n[f]].tobytes() == k.tobytes() and np.array_equal(desc[f, :n[f]], d), pitch
+    finally:
+        ex.close()
