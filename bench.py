@@ -53,6 +53,7 @@ def parse():
                     help="stage reported in `roofline` (auto: largest share of the serialised time)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other frame shapes (KITTI stereo shape, 4K)")
     ap.add_argument("--knn", type=int, default=1 << 20, help="descriptors per side of the 2-NN search")
     return ap.parse_args()
 
@@ -274,9 +275,47 @@ def main():
 
         except Exception as e:  # noqa: BLE001
             out["hamming"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ---- the other frame shapes of the baseline (rank 0 of a single-GPU run): same schedule, smaller batches
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = {}
+        ex.close()
+        frames = d_kps = d_desc = d_n = None
+        torch.cuda.empty_cache()
+        for name, (w2, h2, nf2, b2, ch2) in {"kitti_1241x376_2000kp": (1241, 376, 2000, 1024, 256),
+                                              "uhd_3840x2160_10000kp": (3840, 2160, 10000, 64, 16)}.items():
+            try:
+                e2 = ORBextractor(nf2, 1.2, NLEVELS, 20, 7, max_width=w2, max_height=h2, max_batch=ch2, device=local_rank)
+                e2.set_stream(stream.cuda_stream)
+                cap2 = e2.max_keypoints()
+                pitch = (w2 + 3) // 4 * 4
+                buf = torch.zeros((b2, h2, pitch), dtype=torch.uint8, device=dev)
+                for f0 in range(0, b2, 16):
+                    n = min(16, b2 - f0)
+                    buf[f0:f0 + n, :, :w2] = synth.synth_batch_torch(n, w2, h2, 0x5EED7001 + f0, device=dev)
+                k2 = torch.zeros(b2 * cap2 * 28, dtype=torch.uint8, device=dev)
+                dd2 = torch.zeros(b2 * cap2 * 32, dtype=torch.uint8, device=dev)
+                n2 = torch.zeros(b2, dtype=torch.int32, device=dev)
+                e2.extract_batch_device(buf[:, :, :w2], k2, dd2, n2, cap2)
+                barrier()
+                t1 = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    e2.extract_batch_device(buf[:, :, :w2], k2, dd2, n2, cap2)
+                barrier()
+                dt = time.perf_counter() - t1
+                extra[name] = {"frames_per_s": round(b2 * reps / dt, 1), "frames": b2, "frames_per_pass": ch2,
+                               "mean_keypoints": round(float(n2.float().mean().item()), 1)}
+                e2.close()
+                del buf, k2, dd2, n2
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["other_shapes"] = extra
+        ex = None
     if rank == 0:
         print(json.dumps(out))
-    ex.close()
+    if ex is not None:
+        ex.close()
     if world > 1:
         dist.destroy_process_group()
 
