@@ -384,6 +384,28 @@ int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const o
                                 const float* scale_factors, const float* inv_scale_factors, float mb,
                                 float mbf, float* u_right, float* depth, int* n_stereo, int mem_space);
 
+/* Many independent frame pairs in one call: orbm_search_by_projection for every entry of
+ * `pairs`, each with the meaning of the arguments of the same name above.  Every array a
+ * pair points to is DEVICE memory (the pair table itself is host memory); cur_claimed /
+ * cur_claimed_obs are in/out per pair, query_best may be NULL, nmatches is written on return.
+ * scale_factors (host memory), bf, th and check_orientation are shared by all pairs. */
+typedef struct orbm_projection_pair {
+    orbm_frame cur, last;
+    const uint8_t* mp_desc; /* last.n x 32, or NULL = last.desc */
+    const uint8_t* valid;   /* last.n */
+    const float *u, *v, *invz;
+    const uint8_t* has_obs;
+    const float* cur_u_right; /* cur.n */
+    int32_t direction;
+    int32_t* cur_claimed;     /* cur.n, in/out */
+    uint8_t* cur_claimed_obs; /* cur.n, in/out */
+    int32_t* query_best;      /* last.n or NULL */
+    int32_t nmatches;         /* out */
+} orbm_projection_pair;
+int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs, int npairs,
+                                    const float* scale_factors, int nlevels, float bf, float th,
+                                    int check_orientation);
+
 /* Brute-force 2-nearest-neighbour search over 256-bit descriptors with the
  * serial-scan semantics of the reference's descriptor loops
  * (src/ORBmatcher.cc:255-282): best = smallest distance, lowest train index on

@@ -54,6 +54,13 @@ class Pyramid(C.Structure):
                 ("height", C.c_int32 * MAX_LEVELS), ("pitch", C.c_size_t * MAX_LEVELS)]
 
 
+class ProjectionPair(C.Structure):
+    _fields_ = [("cur", MFrame), ("last", MFrame), ("mp_desc", C.c_void_p), ("valid", C.c_void_p), ("u", C.c_void_p),
+                ("v", C.c_void_p), ("invz", C.c_void_p), ("has_obs", C.c_void_p), ("cur_u_right", C.c_void_p),
+                ("direction", C.c_int32), ("cur_claimed", C.c_void_p), ("cur_claimed_obs", C.c_void_p),
+                ("query_best", C.c_void_p), ("nmatches", C.c_int32)]
+
+
 class FeatureVector(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("n_items", C.c_int32), ("node_ids", C.c_void_p), ("start", C.c_void_p),
                 ("items", C.c_void_p)]
@@ -120,6 +127,7 @@ SIGNATURES = {
     "orbm_distinctive_descriptors": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
     "orbm_compute_stereo_matches": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), C.POINTER(Pyramid),
                                          C.POINTER(Pyramid), _vp, _vp, _f, _f, _vp, _vp, _vp, _i]),
+    "orbm_search_by_projection_batch": (_i, [_vp, C.POINTER(ProjectionPair), _i, _vp, _i, _f, _f, _i]),
     "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
     "orbm_knn2_merge": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
 }

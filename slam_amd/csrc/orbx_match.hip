@@ -52,7 +52,7 @@ __device__ __forceinline__ int wave_excl_count(bool flag, int* total) {
 // Frame::PosInGrid + AssignFeaturesToGrid: one workgroup per frame.  Cell id
 // = ix*48 + iy so that a window's cells of one column are contiguous in the
 // CSR; items inside a cell keep ascending keypoint order.
-__global__ __launch_bounds__(1024) void k_grid_build(DevFrame f, int* cellStart, int* cellItems, u16* cellOf) {
+__device__ __forceinline__ void grid_build_body(DevFrame f, int* cellStart, int* cellItems, u16* cellOf) {
     __shared__ int hist[GRID_CELLS + 1];
     __shared__ int wsum[16];
     const int tid = threadIdx.x;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_window(DevFrame train, const int* __res
 }
 
 // Exclusive scan of n ints by one workgroup (n is a few thousand).
-__global__ __launch_bounds__(1024) void k_scan(const int* in, int* out, int n) {
+__device__ __forceinline__ void scan_body(const int* in, int* out, int n) {
     __shared__ int wsum[16];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -296,7 +296,7 @@ __device__ __forceinline__ bool projq_query(const ProjQueries& q, int i, Query* 
 
 // Candidate lists of every query (mode 0: counts; mode 2: CSR fill with distances).
 // The right-image gate is state-free and applied here.
-__global__ __launch_bounds__(256) void k_projq_candidates(DevFrame train, const int* __restrict__ cellStart,
+__device__ __forceinline__ void projq_candidates_body(DevFrame train, const int* __restrict__ cellStart,
                                                            const int* __restrict__ cellItems,
                                                            const float* __restrict__ trainURight, ProjQueries q, int mode,
                                                            const int* __restrict__ offs, int* candIdx, int* candDist,
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_projq_candidates(DevFrame train, const 
 
 // Per-query inputs of SearchByProjection(cur, last): reference src/ORBmatcher.cc:1564-1598,
 // 1615-1621.  One thread per last-frame keypoint.
-__global__ void k_m4_queries(DevFrame cur, DevFrame last, const u8* valid, const float* u, const float* v,
+__device__ __forceinline__ void m4_queries_body(DevFrame cur, DevFrame last, const u8* valid, const float* u, const float* v,
                              const float* invz, const float* scaleFactors, float bf, float th, int direction,
                              u8* qValid, float* qRadius, int* qMin, int* qMax, float* qAngle, float* qUR) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,7 +406,7 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) {
 // and the pyramid level of the keypoint holding it are reproduced as the sequential scan
 // leaves them: when the final best arrives the previous best becomes second; afterwards
 // only a strictly smaller distance replaces it.
-__global__ __launch_bounds__(64) void k_projq_resolve(DevFrame train, ProjQueries q, ProjPolicy pol,
+__device__ __forceinline__ void projq_resolve_body(DevFrame train, ProjQueries q, ProjPolicy pol,
                                                         const int* __restrict__ offs, const int* __restrict__ candIdx,
                                                         const int* __restrict__ candDist, int* claimed, u8* claimedObs,
                                                         int* qBest, int* qBin, int* nmatchesOut) {
@@ -501,6 +501,73 @@ __global__ __launch_bounds__(64) void k_projq_resolve(DevFrame train, ProjQuerie
         nmatches -= removed;
     }
     if (lane == 0) *nmatchesOut = nmatches;
+}
+
+// ---- kernels over the bodies above: one problem per launch, or one problem ("job") per
+// blockIdx.y / blockIdx.x for batches of independent frame pairs
+struct ProjJob {
+    DevFrame train, last;            // train = the frame that is searched; last = source of the queries (M4 only)
+    const float* trainURight;
+    ProjQueries q;
+    int *cellStart, *cellItems;
+    u16* cellOf;
+    int *counts, *offs, *candIdx, *candDist;
+    int* claimed;
+    u8* claimedObs;
+    int *qBest, *qBin, *nmatches;
+    // inputs of the frame-to-frame form (reference src/ORBmatcher.cc:1533-1678)
+    const u8* m4Valid;
+    const float *m4U, *m4V, *m4Invz;
+    int direction;
+    u8* qValid;
+    float *qRadius, *qAngle, *qUR;
+    int *qMin, *qMax;
+};
+
+__global__ __launch_bounds__(1024) void k_grid_build(DevFrame f, int* cellStart, int* cellItems, u16* cellOf) {
+    grid_build_body(f, cellStart, cellItems, cellOf);
+}
+__global__ __launch_bounds__(1024) void k_grid_build_jobs(const ProjJob* __restrict__ jobs) {
+    const ProjJob& J = jobs[blockIdx.x];
+    grid_build_body(J.train, J.cellStart, J.cellItems, J.cellOf);
+}
+__global__ __launch_bounds__(1024) void k_scan(const int* in, int* out, int n) { scan_body(in, out, n); }
+__global__ __launch_bounds__(1024) void k_scan_jobs(const ProjJob* __restrict__ jobs, int* totals) {
+    const ProjJob& J = jobs[blockIdx.x];
+    scan_body(J.counts, J.offs, J.q.n);
+    __syncthreads();
+    if (threadIdx.x == 0) totals[blockIdx.x] = J.offs[J.q.n];
+}
+__global__ __launch_bounds__(256) void k_projq_candidates(DevFrame train, const int* __restrict__ cellStart,
+                                                           const int* __restrict__ cellItems,
+                                                           const float* __restrict__ trainURight, ProjQueries q, int mode,
+                                                           const int* __restrict__ offs, int* candIdx, int* candDist,
+                                                           int* counts) {
+    projq_candidates_body(train, cellStart, cellItems, trainURight, q, mode, offs, candIdx, candDist, counts);
+}
+__global__ __launch_bounds__(256) void k_projq_candidates_jobs(const ProjJob* __restrict__ jobs, int mode) {
+    const ProjJob& J = jobs[blockIdx.y];
+    projq_candidates_body(J.train, J.cellStart, J.cellItems, J.trainURight, J.q, mode, J.offs, J.candIdx, J.candDist, J.counts);
+}
+__global__ void k_m4_queries(DevFrame cur, DevFrame last, const u8* valid, const float* u, const float* v,
+                             const float* invz, const float* scaleFactors, float bf, float th, int direction,
+                             u8* qValid, float* qRadius, int* qMin, int* qMax, float* qAngle, float* qUR) {
+    m4_queries_body(cur, last, valid, u, v, invz, scaleFactors, bf, th, direction, qValid, qRadius, qMin, qMax, qAngle, qUR);
+}
+__global__ void k_m4_queries_jobs(const ProjJob* __restrict__ jobs, const float* scaleFactors, float bf, float th) {
+    const ProjJob& J = jobs[blockIdx.y];
+    m4_queries_body(J.train, J.last, J.m4Valid, J.m4U, J.m4V, J.m4Invz, scaleFactors, bf, th, J.direction, J.qValid, J.qRadius,
+                    J.qMin, J.qMax, J.qAngle, J.qUR);
+}
+__global__ __launch_bounds__(64) void k_projq_resolve(DevFrame train, ProjQueries q, ProjPolicy pol,
+                                                        const int* __restrict__ offs, const int* __restrict__ candIdx,
+                                                        const int* __restrict__ candDist, int* claimed, u8* claimedObs,
+                                                        int* qBest, int* qBin, int* nmatchesOut) {
+    projq_resolve_body(train, q, pol, offs, candIdx, candDist, claimed, claimedObs, qBest, qBin, nmatchesOut);
+}
+__global__ __launch_bounds__(64) void k_projq_resolve_jobs(const ProjJob* __restrict__ jobs, ProjPolicy pol) {
+    const ProjJob& J = jobs[blockIdx.x];
+    projq_resolve_body(J.train, J.q, pol, J.offs, J.candIdx, J.candDist, J.claimed, J.claimedObs, J.qBest, J.qBin, J.nmatches);
 }
 
 // ------------------------------------------------------------------ SearchForInitialization
@@ -1383,6 +1450,8 @@ struct orbm_context {
     hipStream_t ownStream = nullptr, stream = nullptr;
     // grow-only scratch, one block per purpose
     std::vector<std::pair<void*, size_t>> pool;
+    std::vector<unsigned char> jobsHost;  // host image of the job table of a batched call
+    std::vector<int> totalsHost;
 };
 
 namespace {
@@ -1411,7 +1480,7 @@ enum {
     SL_ST_U, SL_ST_D, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, SL_BW_VALID1,
     SL_BW_VALID2, SL_BW_M12, SL_BW_M21, SL_BW_BIN, SL_BW_HIST, SL_BW_UR1, SL_BW_UR2, SL_WB_LEVEL, SL_WB_IDX, SL_WB_DIST,
     SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2, SL_DD_DESC, SL_DD_START, SL_DD_BEST, SL_DD_MED, SL_DD_OUT,
-    SL_MK_MASK, SL_MK_KPS, SL_MK_DESC, SL_RC_REC, SL_RC_IDX
+    SL_MK_MASK, SL_MK_KPS, SL_MK_DESC, SL_RC_REC, SL_RC_IDX, SL_JB_JOBS, SL_JB_I32, SL_JB_U8, SL_JB_TOT, SL_JB_SF
 };
 
 // Device view of a caller array: the pointer itself for device memory, else a staged copy.
@@ -1829,6 +1898,132 @@ int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm
     dq.rightGate = (const float*)qr;  // er > radius rejects (reference :1619)
     ProjPolicy pol = {0, TH_HIGH, 0, 0.f, check_orientation};
     return run_projected(m, dc, dUR, dq, pol, cur_claimed, cur_claimed_obs, query_best, nmatches, mem_space);
+}
+
+int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs, int npairs, const float* scale_factors,
+                                    int nlevels, float bf, float th, int check_orientation) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (npairs < 0 || (npairs > 0 && !pairs) || !scale_factors || nlevels < 1 || nlevels > ORBM_MAX_LEVELS) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (npairs == 0) return ORBX_OK;
+    // scratch layout: 32-bit words and bytes, one slice per pair
+    size_t words = 0, bytes = 0;
+    int maxNl = 0;
+    for (int i = 0; i < npairs; i++) {
+        const orbm_projection_pair& P = pairs[i];
+        if (P.cur.n < 0 || P.last.n < 0 || P.cur.n > 65000 || P.last.n > 65000 ||
+            (P.last.n > 0 && (!P.valid || !P.u || !P.v || !P.invz || !P.has_obs || !P.last.kps || !P.last.desc)) ||
+            (P.cur.n > 0 && (!P.cur_u_right || !P.cur_claimed || !P.cur_claimed_obs || !P.cur.kps || !P.cur.desc))) {
+            orbx_set_error("pair %d: invalid argument", i);
+            return ORBX_ERR_INVALID;
+        }
+        const size_t nl = (size_t)P.last.n, nc = (size_t)P.cur.n;
+        words += (GRID_CELLS + 1) + nc + nl + (nl + 1) + 7 * nl + 1 + 8;  // cellStart, cellItems, counts, offs, qBin/qMin/qMax/qBest/qRadius/qAngle/qUR, nmatches
+        bytes += 2 * nc + nl + 16;                                       // cellOf, qValid
+        maxNl = std::max(maxNl, P.last.n);
+    }
+    void *dJobs, *dWords, *dBytes, *dTot, *dSf;
+    if ((rc = pool_get(m, SL_JB_JOBS, (size_t)npairs * sizeof(ProjJob), &dJobs)) ||
+        (rc = pool_get(m, SL_JB_I32, words * 4, &dWords)) || (rc = pool_get(m, SL_JB_U8, bytes, &dBytes)) ||
+        (rc = pool_get(m, SL_JB_TOT, (size_t)npairs * 2 * sizeof(int), &dTot)) ||
+        (rc = pool_get(m, SL_JB_SF, ORBM_MAX_LEVELS * sizeof(float), &dSf)))
+        return rc;
+    ORBX_HIP_CHECK(hipMemcpyAsync(dSf, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    m->jobsHost.resize((size_t)npairs * sizeof(ProjJob));
+    ProjJob* jobs = reinterpret_cast<ProjJob*>(m->jobsHost.data());
+    int* wp = (int*)dWords;
+    u8* bp = (u8*)dBytes;
+    int* nmArr = (int*)dTot + npairs;
+    for (int i = 0; i < npairs; i++) {
+        const orbm_projection_pair& P = pairs[i];
+        ProjJob& J = jobs[i];
+        memset(&J, 0, sizeof(J));
+        if ((rc = make_frame(m, &P.cur, 0, 0, ORBX_MEM_DEVICE, &J.train))) return rc;
+        if ((rc = make_frame(m, &P.last, 0, 0, ORBX_MEM_DEVICE, &J.last))) return rc;
+        const int nl = P.last.n, nc = P.cur.n;
+        auto takeW = [&](size_t n) {
+            int* r = wp;
+            wp += n;
+            return r;
+        };
+        J.trainURight = P.cur_u_right;
+        J.cellStart = takeW(GRID_CELLS + 1);
+        J.cellItems = takeW((size_t)nc);
+        J.counts = takeW((size_t)nl);
+        J.offs = takeW((size_t)nl + 1);
+        J.qBin = takeW((size_t)nl);
+        J.qMin = takeW((size_t)nl);
+        J.qMax = takeW((size_t)nl);
+        int* ownBest = takeW((size_t)nl);
+        J.qRadius = (float*)takeW((size_t)nl);
+        J.qAngle = (float*)takeW((size_t)nl);
+        J.qUR = (float*)takeW((size_t)nl);
+        wp += 8;
+        J.cellOf = (u16*)bp;
+        bp += 2 * (size_t)nc;
+        J.qValid = bp;
+        bp += (size_t)nl;
+        bp = (u8*)(((uintptr_t)bp + 15) & ~(uintptr_t)15);
+        J.claimed = (int*)P.cur_claimed;
+        J.claimedObs = P.cur_claimed_obs;
+        J.qBest = P.query_best ? (int*)P.query_best : ownBest;
+        J.nmatches = nmArr + i;
+        J.m4Valid = P.valid;
+        J.m4U = P.u;
+        J.m4V = P.v;
+        J.m4Invz = P.invz;
+        J.direction = P.direction;
+        J.q.n = nl;
+        J.q.valid = J.qValid;
+        J.q.u = P.u;
+        J.q.v = P.v;
+        J.q.radius = J.qRadius;
+        J.q.minLevel = J.qMin;
+        J.q.maxLevel = J.qMax;
+        J.q.desc = P.mp_desc ? P.mp_desc : P.last.desc;
+        J.q.angle = J.qAngle;
+        J.q.hasObs = P.has_obs;
+        J.q.uRight = J.qUR;
+        J.q.rightGate = J.qRadius;  // er > radius rejects (reference src/ORBmatcher.cc:1619)
+    }
+    const size_t jobBytes = (size_t)npairs * sizeof(ProjJob);
+    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
+    const ProjJob* dJ = (const ProjJob*)dJobs;
+    hipLaunchKernelGGL(k_grid_build_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ);
+    if (maxNl > 0) {
+        hipLaunchKernelGGL(k_m4_queries_jobs, dim3((maxNl + 255) / 256, npairs), dim3(256), 0, m->stream, dJ, (const float*)dSf, bf,
+                           th);
+        hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, 0);
+    }
+    hipLaunchKernelGGL(k_scan_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ, (int*)dTot);
+    ORBX_HIP_CHECK(hipGetLastError());
+    m->totalsHost.resize((size_t)npairs);
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->totalsHost.data(), dTot, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    size_t total = 0;
+    for (int i = 0; i < npairs; i++) total += (size_t)m->totalsHost[i];
+    void *cIdx, *cDist;
+    if ((rc = pool_get(m, SL_CAND_IDX, std::max(total, (size_t)1) * 4, &cIdx)) ||
+        (rc = pool_get(m, SL_CAND_DIST, std::max(total, (size_t)1) * 4, &cDist)))
+        return rc;
+    size_t off = 0;
+    for (int i = 0; i < npairs; i++) {
+        jobs[i].candIdx = (int*)cIdx + off;
+        jobs[i].candDist = (int*)cDist + off;
+        off += (size_t)m->totalsHost[i];
+    }
+    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
+    if (maxNl > 0) hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, 2);
+    ProjPolicy pol = {0, TH_HIGH, 0, 0.f, check_orientation};
+    hipLaunchKernelGGL(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
+    ORBX_HIP_CHECK(hipGetLastError());
+    ORBX_HIP_CHECK(hipMemcpyAsync(m->totalsHost.data(), nmArr, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < npairs; i++) pairs[i].nmatches = m->totalsHost[i];
+    return ORBX_OK;
 }
 
 static int fill_pyramid(const orbm_pyramid* p, DevPyramid* d, const char* which) {

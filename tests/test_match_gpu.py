@@ -347,3 +347,66 @@ def test_search_by_projection_frames_with_map_point_descriptors(oracle, frames):
     assert n == rn and np.array_equal(cl, rcl) and np.array_equal(co, rco)
     assert np.array_equal(qb, rqb) and (qb >= 0).sum() >= n
     m.close()
+
+
+def test_search_by_projection_batch_equals_oracle_per_pair(oracle, frames):
+    """Many independent frame pairs in one call (device-resident): every pair must equal the
+    oracle's result for that pair, including pairs with empty frames, other directions, map-point
+    descriptors and prior claims."""
+    import torch
+    from slam_amd.matcher import ORBmatcher
+    (ka, da), (kb, db) = frames["a"], frames["b"]
+    sf = frames["sf"]
+    bf, th = 40.0, 15.0
+    cases = []
+    for i in range(9):
+        valid, u, v, invz, has_obs, ur = projection_inputs(frames, 100 + i)
+        c = dict(ka=ka, da=da, kb=kb, db=db, valid=valid, u=u, v=v, invz=invz, has_obs=has_obs, ur=ur,
+                 direction=i % 3, mpd=synth.perturb_descriptors(da, 50 + i, 25) if i % 2 else None,
+                 claimed=np.full(len(kb), -1, np.int32), claimed_obs=np.zeros(len(kb), np.uint8))
+        if i == 4:   # prior claims
+            rng = np.random.RandomState(3)
+            pick = rng.uniform(size=len(kb)) < 0.2
+            c["claimed"][pick] = 7
+            c["claimed_obs"][pick] = (rng.uniform(size=pick.sum()) < 0.5).astype(np.uint8)
+        if i == 6:   # shorter last frame
+            n = 300
+            for k in ("valid", "u", "v", "invz", "has_obs"):
+                c[k] = c[k][:n]
+            c["ka"], c["da"] = ka[:n], da[:n]
+            if c["mpd"] is not None:
+                c["mpd"] = c["mpd"][:n]
+        if i == 7:   # empty last frame
+            for k in ("valid", "u", "v", "invz", "has_obs"):
+                c[k] = c[k][:0]
+            c["ka"], c["da"], c["mpd"] = ka[:0], da[:0], None
+        cases.append(c)
+    dev = "cuda"
+    keep, pairs = [], []
+    for c in cases:
+        t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        p = dict(cur_kps=t(c["kb"].view(np.uint8).reshape(-1, 28)), cur_desc=t(c["db"]),
+                 last_kps=t(c["ka"].view(np.uint8).reshape(-1, 28)), last_desc=t(c["da"].reshape(-1, 32)),
+                 valid=t(c["valid"]), u=t(c["u"]), v=t(c["v"]), invz=t(c["invz"]), has_obs=t(c["has_obs"]),
+                 cur_u_right=t(c["ur"]), claimed=t(c["claimed"]), claimed_obs=t(c["claimed_obs"]),
+                 query_best=torch.full((max(len(c["ka"]), 1),), -5, dtype=torch.int32, device=dev),
+                 mp_desc=t(c["mpd"]) if c["mpd"] is not None else None, direction=c["direction"], bounds=BOUNDS)
+        pairs.append(p)
+    m = ORBmatcher(0.9, True)
+    try:
+        torch.cuda.synchronize()
+        counts = m.SearchByProjectionBatch(pairs, sf, bf, th)
+        torch.cuda.synchronize()
+    finally:
+        m.close()
+    for c, p, n in zip(cases, pairs, counts):
+        ocur = oracle.FrameData(c["kb"], c["db"], BOUNDS, sf)
+        olast = oracle.FrameData(c["ka"], c["da"].reshape(-1, 32), BOUNDS, sf)
+        cl0, co0 = c["claimed"].copy(), c["claimed_obs"].copy()
+        rn, rcl, rco, rqb = oracle.search_by_projection_frames(ocur, olast, c["valid"], c["u"], c["v"], c["invz"], c["has_obs"],
+                                                               c["ur"], bf, th, c["direction"], True, mp_desc=c["mpd"],
+                                                               return_query_best=True, claimed=cl0, claimed_obs=co0)
+        assert n == rn
+        assert np.array_equal(p["claimed"].cpu().numpy(), rcl) and np.array_equal(p["claimed_obs"].cpu().numpy(), rco)
+        assert np.array_equal(p["query_best"].cpu().numpy()[:len(c["ka"])], rqb)
+    assert sum(counts) > 500
