@@ -275,6 +275,54 @@ def main():
 
         except Exception as e:  # noqa: BLE001
             out["hamming"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ---- windowed matcher throughput: frame-to-frame SearchByProjection over many independent pairs
+    # in one call (each frame against itself, projections = keypoint positions + 1 px noise).
+    if rank == 0 and world == 1 and not args.no_hamming:
+        try:
+            mp = ORBmatcher(0.9, True, device=local_rank)
+            mp.set_stream(stream.cuda_stream)
+            NP = min(1024, B)
+            nk = d_n[:NP].cpu().numpy()
+            kview = d_kps.view(B, cap, 28)
+            dview = d_desc.view(B, cap, 32)
+            fl = kview[:NP].contiguous().view(torch.float32).view(NP, cap, 7)
+            g2 = torch.Generator(device=dev)
+            g2.manual_seed(7)
+            uu = (fl[:, :, 0] + torch.randn((NP, cap), device=dev, generator=g2)).contiguous()
+            vv = (fl[:, :, 1] + torch.randn((NP, cap), device=dev, generator=g2)).contiguous()
+            ones8 = torch.ones((NP, cap), dtype=torch.uint8, device=dev)
+            invz = torch.full((NP, cap), 0.5, dtype=torch.float32, device=dev)
+            ur = torch.full((NP, cap), -1.0, dtype=torch.float32, device=dev)
+            claimed = torch.full((NP, cap), -1, dtype=torch.int32, device=dev)
+            cobs = torch.zeros((NP, cap), dtype=torch.uint8, device=dev)
+            pairs = []
+            for i in range(NP):
+                n = int(nk[i])
+                pairs.append(dict(cur_kps=kview[i, :n], cur_desc=dview[i, :n], last_kps=kview[i, :n], last_desc=dview[i, :n],
+                                  valid=ones8[i, :n], u=uu[i, :n], v=vv[i, :n], invz=invz[i, :n], has_obs=ones8[i, :n],
+                                  cur_u_right=ur[i, :n], claimed=claimed[i, :n], claimed_obs=cobs[i, :n], direction=0,
+                                  bounds=(0.0, 0.0, float(W), float(H))))
+            sfac = ex.GetScaleFactors()
+            pairs = mp.projection_pair_table(pairs)
+            counts = mp.SearchByProjectionBatch(pairs, sfac, 40.0, 7.0)
+            barrier()
+            reps = 3
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                claimed.fill_(-1)
+                cobs.zero_()
+                counts = mp.SearchByProjectionBatch(pairs, sfac, 40.0, 7.0)
+            barrier()
+            dt = time.perf_counter() - t1
+            out["projection_search"] = {"queries_per_s": round(float(nk.sum()) * reps / dt, 1), "pairs": NP,
+                                        "queries_per_pair": round(float(nk.mean()), 1), "th": 7.0,
+                                        "matches_per_pair": round(float(np.mean(counts)), 1),
+                                        "note": "orbm_search_by_projection_batch, device-resident"}
+            mp.close()
+            del pairs, uu, vv, ones8, invz, ur, claimed, cobs, fl
+        except Exception as e:  # noqa: BLE001
+            out["projection_search"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- the other frame shapes of the baseline (rank 0 of a single-GPU run): same schedule, smaller batches
     if rank == 0 and world == 1 and not args.no_extra:
         extra = {}

@@ -222,12 +222,10 @@ class ORBmatcher:
         return self.search_projected(KF, (np.asarray(valid, bool) & inimg).astype(np.uint8), u, v, radius,
                                      level - 1, level, desc, pol, claimed=matched)
 
-    def SearchByProjectionBatch(self, pairs, scale_factors, bf, th):
-        """Frame-to-frame SearchByProjection (reference src/ORBmatcher.cc:1533-1678) for many
-        independent pairs in one call.  `pairs`: list of dicts of torch DEVICE tensors with keys
-        cur_kps (n, 28) u8, cur_desc (n, 32) u8, last_kps, last_desc, valid u8, u, v, invz f32,
-        has_obs u8, cur_u_right f32, claimed i32, claimed_obs u8 (both in/out), optional mp_desc and
-        query_best i32, direction int, bounds (4 floats).  Returns the list of match counts."""
+    @staticmethod
+    def projection_pair_table(pairs):
+        """The C table of orbm_search_by_projection_batch for a list of pair dicts (see
+        SearchByProjectionBatch); reusable across calls while the tensors stay alive."""
         arr = (_lib.ProjectionPair * len(pairs))()
         for i, p in enumerate(pairs):
             b = p["bounds"]
@@ -240,10 +238,20 @@ class ORBmatcher:
             arr[i].cur_claimed = p["claimed"].data_ptr()
             arr[i].cur_claimed_obs = p["claimed_obs"].data_ptr()
             arr[i].query_best = p["query_best"].data_ptr() if p.get("query_best") is not None else None
+        return arr
+
+    def SearchByProjectionBatch(self, pairs, scale_factors, bf, th):
+        """Frame-to-frame SearchByProjection (reference src/ORBmatcher.cc:1533-1678) for many
+        independent pairs in one call.  `pairs`: a table from projection_pair_table, or a list of
+        dicts of torch DEVICE tensors with keys cur_kps (n, 28) u8, cur_desc (n, 32) u8, last_kps,
+        last_desc, valid u8, u, v, invz f32, has_obs u8, cur_u_right f32, claimed i32, claimed_obs u8
+        (both in/out), optional mp_desc and query_best i32, direction int, bounds (4 floats).
+        Returns the list of match counts."""
+        arr = self.projection_pair_table(pairs) if isinstance(pairs, list) else pairs
         sf = np.ascontiguousarray(scale_factors, np.float32)
-        check(self._lib.orbm_search_by_projection_batch(self._m, arr, len(pairs), sf.ctypes.data, len(sf), float(bf),
+        check(self._lib.orbm_search_by_projection_batch(self._m, arr, len(arr), sf.ctypes.data, len(sf), float(bf),
                                                         float(th), int(self.mbCheckOrientation)))
-        return [arr[i].nmatches for i in range(len(pairs))]
+        return [arr[i].nmatches for i in range(len(arr))]
 
     # ---- vocabulary-guided searches
     @staticmethod
