@@ -230,7 +230,13 @@ def main():
                          "mismatched_descriptors": bad_desc}
 
     # ---- Hamming pairs/s: brute-force 2-NN, train rows sharded over ranks.  A failure here
-    # must not lose the headline line.
+    # must not lose the headline line: on more than one GPU this leg has a collective exchange, so
+    # the JSON line goes out first and the Hamming result follows on stderr (and in
+    # gpurun_out/hamming_N.json when that directory exists).
+    headline_printed = False
+    if world > 1 and rank == 0:
+        print(json.dumps(out), flush=True)
+        headline_printed = True
     if not args.no_hamming:
         try:
             m = ORBmatcher(0.6, True, device=local_rank)
@@ -361,7 +367,16 @@ def main():
         out["other_shapes"] = extra
         ex = None
     if rank == 0:
-        print(json.dumps(out))
+        if not headline_printed:
+            print(json.dumps(out), flush=True)
+        elif "hamming" in out:
+            print("hamming: " + json.dumps(out["hamming"]), file=sys.stderr, flush=True)
+            try:
+                d = os.path.join(ROOT, "gpurun_out")
+                if os.path.isdir(d):
+                    json.dump(out["hamming"], open(os.path.join(d, "hamming_%d.json" % world), "w"))
+            except OSError:
+                pass
     if ex is not None:
         ex.close()
     if world > 1:

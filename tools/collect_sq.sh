@@ -7,9 +7,9 @@ OUT=gpurun_out/sq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE \
-    --output-format csv -d $OUT/a -o a -- python3 bench.py --steps 1 --warmup 1 --frames 512 --no-cpu --no-hamming > $OUT/a.log 2>&1
+    --output-format csv -d $OUT/a -o a -- python3 bench.py --steps 1 --warmup 1 --frames 512 --no-cpu --no-hamming --no-extra > $OUT/a.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM \
-    --output-format csv -d $OUT/b -o b -- python3 bench.py --steps 1 --warmup 1 --frames 512 --no-cpu --no-hamming > $OUT/b.log 2>&1
+    --output-format csv -d $OUT/b -o b -- python3 bench.py --steps 1 --warmup 1 --frames 512 --no-cpu --no-hamming --no-extra > $OUT/b.log 2>&1
 python3 - $OUT <<'PY'
 import collections, csv, glob, os, re, sys
 out = sys.argv[1]
