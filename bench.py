@@ -69,6 +69,7 @@ def main():
     rank, local_rank, world = sdist.init_process_group()
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)  # more ranks than GPUs only happens in rehearsals
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -276,7 +277,8 @@ def main():
             int_peak = 256 * 4 * 32 * 2.4e9  # lanes x clock: 32-bit integer ops/s
             out["hamming"] = {"pairs_per_s": round(pairs / dt, 1), "nq": nq_l * world, "nt": NT,
                               "int_ops_per_pair": 16, "frac_of_int_valu_peak": round(pairs / dt * 16 / (int_peak * world), 4),
-                              "exchange": "all-gather queries + all-to-all partials (RCCL)" if world > 1 else "none"}
+                              "exchange": ("all-gather queries + all-to-all partials (RCCL)" if torch.distributed.get_backend() == "nccl"
+                                           else "all-gather queries + all-gather partials (gloo rehearsal)") if world > 1 else "none"}
             m.close()
 
         except Exception as e:  # noqa: BLE001

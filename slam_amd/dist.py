@@ -26,7 +26,8 @@ def init_process_group(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ORBX_DIST_BACKEND=gloo lets several ranks rehearse on one GPU (RCCL wants one GPU per rank)
+            backend = os.environ.get("ORBX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
