@@ -602,6 +602,12 @@ int extract(const oracle_params& p, const Tables& t, const uint8_t* img, int w, 
         const int maxBorderX = L.w - EDGE_THRESHOLD + 3;
         const int maxBorderY = L.h - EDGE_THRESHOLD + 3;
         detect_cells(L.d.data(), L.w, L.h, L.w, p.ini_th_fast, p.min_th_fast, cands);
+        // A level more than twice as tall as wide has round(width / height) = 0 initial nodes:
+        // the reference (src/ORBextractor.cc:553-555) then divides by zero and indexes an
+        // empty vector.  Reported as an error instead of reproduced.
+        if (!cands.empty() && maxBorderY > minBorderY &&
+            (int)round(static_cast<float>(maxBorderX - minBorderX) / (maxBorderY - minBorderY)) < 1)
+            return -3;
         distribute(cands, minBorderX, maxBorderX, minBorderY, maxBorderY, t.quotas[level], sel);
         const int scaledPatchSize = PATCH_SIZE * t.scale[level];
         for (int idx : sel) {
@@ -730,6 +736,7 @@ int oracle_distribute(const int* xs, const int* ys, const int* resp, int n, int 
     std::vector<Cand> c(n);
     for (int i = 0; i < n; i++) c[i] = {xs[i], ys[i], resp[i]};
     std::vector<int> sel;
+    if (n > 0 && (max_y <= min_y || (int)round(static_cast<float>(max_x - min_x) / (max_y - min_y)) < 1)) return -3;
     distribute(c, min_x, max_x, min_y, max_y, n_target, sel);
     int m = std::min((int)sel.size(), cap);
     for (int i = 0; i < m; i++) out_idx[i] = sel[i];

@@ -305,3 +305,43 @@ def test_width_not_multiple_of_four_device_resident(oracle):
                 assert kps[f, :n[f]].tobytes() == k.tobytes() and np.array_equal(desc[f, :n[f]], d), pitch
     finally:
         ex.close()
+
+
+def test_random_configurations_equal_oracle():
+    """A seeded sweep over image sizes, level counts, scale factors, thresholds and image
+    statistics (tools/fuzz_extract.py runs the same generator for as long as asked)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_extract.py")
+    spec = importlib.util.spec_from_file_location("fuzz_extract", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from slam_amd._lib import OrbxError
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 120:
+        c = fz.draw(rng)
+        try:
+            err, _ = fz.run_one(c)
+        except OrbxError as e:
+            assert "LDS budget" in str(e), (c, e)
+            continue
+        assert err is None, "%s for %r" % (err, c)
+        done += 1
+
+
+def test_level_taller_than_twice_its_width_is_rejected(oracle):
+    # round(width / height) of the detection area is the number of initial quadtree nodes
+    # (reference src/ORBextractor.cc:553); at 0 the reference divides by zero.  Both sides
+    # report an error instead.
+    from slam_amd._lib import OrbxError
+    from slam_amd.extractor import ORBextractor
+    img = synth.synth_image(332, 668, 3)
+    with pytest.raises(RuntimeError):
+        oracle.extract(oracle.params(nfeatures=500, nlevels=1), img)
+    with pytest.raises(OrbxError):
+        ex = ORBextractor(500, 1.2, 1, 20, 7, max_width=332, max_height=668, max_batch=1)
+        try:
+            ex(img, None)
+        finally:
+            ex.close()
