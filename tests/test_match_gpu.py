@@ -410,3 +410,21 @@ def test_search_by_projection_batch_equals_oracle_per_pair(oracle, frames):
         assert np.array_equal(p["claimed"].cpu().numpy(), rcl) and np.array_equal(p["claimed_obs"].cpu().numpy(), rco)
         assert np.array_equal(p["query_best"].cpu().numpy()[:len(c["ka"])], rqb)
     assert sum(counts) > 500
+
+
+def test_random_frames_and_parameters_equal_oracle():
+    """A seeded sweep over synthetic frame pairs (empty and tiny frames, clustered keypoints,
+    non-zero image bounds, descriptors with many equal distances) and over the parameters of
+    every search; tools/fuzz_match.py runs the same generator for as long as asked."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_match.py")
+    spec = importlib.util.spec_from_file_location("fuzz_match", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for case in range(250):
+        rng = np.random.default_rng(77000 + case)
+        c = fz.draw_case(rng)
+        err = fz.run_case(rng, c)
+        assert err is None, "case seed %d: %s" % (77000 + case, err)
+    assert fz.STATS["proj n"] > 10000 and fz.STATS["bow n"] > 5000
