@@ -121,3 +121,20 @@ def test_stereo_arbitrary_keypoints(oracle):
         m.close()
         el.close()
         er.close()
+
+
+def test_random_stereo_configurations_equal_oracle():
+    """A seeded sweep over image sizes, pyramid shapes, disparity ranges, noise and baselines
+    (tools/fuzz_stereo.py runs the same generator for as long as asked)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_stereo.py")
+    spec = importlib.util.spec_from_file_location("fuzz_stereo", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(4242)
+    for case in range(60):
+        c = fz.draw(rng)
+        err = fz.run_one(c)
+        assert err is None, "%s for %r" % (err, c)
+    assert fz.STATS["points"] > 5000
