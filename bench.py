@@ -212,6 +212,11 @@ def main():
                                "sample": "first %d of the benchmark's frames, oracle (C++ restatement of the "
                                          "reference path, not OpenCV), frame-parallel std::thread" % S,
                                "single_thread_frames_per_s": round(s1 / cpu_1t, 2)}
+        s2 = min(64, S)
+        st_cpu = O.extract_stages(p, host[:s2])
+        tot_cpu = sum(st_cpu.values()) or 1.0
+        out["cpu_baseline"]["single_thread_stage_share"] = {k: round(v / tot_cpu, 3) for k, v in st_cpu.items()}
+        out["cpu_baseline"]["single_thread_ms_per_frame"] = round(tot_cpu / s2 * 1e3, 2)
         n = d_n[:S].cpu().numpy()
         kps = d_kps[:S * cap * 28].cpu().numpy().view(KP_DTYPE).reshape(S, cap)
         desc = d_desc[:S * cap * 32].cpu().numpy().reshape(S, cap, 32)

@@ -23,6 +23,7 @@
 #include <list>
 #include <thread>
 #include <utility>
+#include <chrono>
 #include <vector>
 
 #include "../include/orbx_pattern_31.h"
@@ -179,21 +180,30 @@ void gaussian7(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, s
     static const int K257[7] = {18, 34, 49, 55, 49, 34, 18};
     static const int K256[7] = {18, 34, 48, 56, 48, 34, 18};
     const int* k = variant == 1 ? K256 : K257;
-    std::vector<int> rows((size_t)w * h);
+    // row sums fit 16 bits (257 * 255 = 65535)
+    std::vector<uint16_t> rows((size_t)w * h);
     for (int y = 0; y < h; y++) {
         const uint8_t* S = src + (size_t)y * sstride;
-        for (int x = 0; x < w; x++) {
+        uint16_t* R = rows.data() + (size_t)y * w;
+        const int x0 = std::min(3, w), x1 = std::max(w - 3, x0);
+        auto edge = [&](int x) {
             int s = 0;
             for (int i = -3; i <= 3; i++) s += k[i + 3] * S[reflect101(x + i, w)];
-            rows[(size_t)y * w + x] = s;
-        }
+            R[x] = (uint16_t)s;
+        };
+        for (int x = 0; x < x0; x++) edge(x);
+        for (int x = x0; x < x1; x++)
+            R[x] = (uint16_t)(k[0] * (S[x - 3] + S[x + 3]) + k[1] * (S[x - 2] + S[x + 2]) + k[2] * (S[x - 1] + S[x + 1]) +
+                              k[3] * S[x]);
+        for (int x = x1; x < w; x++) edge(x);
     }
     for (int y = 0; y < h; y++) {
         uint8_t* D = dst + (size_t)y * dstride;
+        const uint16_t* r[7];
+        for (int i = -3; i <= 3; i++) r[i + 3] = rows.data() + (size_t)reflect101(y + i, h) * w;
         for (int x = 0; x < w; x++) {
-            int s = 0;
-            for (int i = -3; i <= 3; i++) s += k[i + 3] * rows[(size_t)reflect101(y + i, h) * w + x];
-            int v = (s + 32768) >> 16;
+            const int s = k[0] * (r[0][x] + r[6][x]) + k[1] * (r[1][x] + r[5][x]) + k[2] * (r[2][x] + r[4][x]) + k[3] * r[3][x];
+            const int v = (s + 32768) >> 16;
             D[x] = (uint8_t)std::min(v, 255);
         }
     }
@@ -587,12 +597,24 @@ void build_pyramid(const Tables& t, const uint8_t* img, int w, int h, size_t str
 
 // reference src/ORBextractor.cc:1052-1114 (operator()) with :772-863
 // (ComputeKeyPointsOctTree) inlined.
+// stage_s, when given, accumulates wall-clock seconds per stage: pyramid, FAST cells, quadtree,
+// orientation, blur, descriptors (std::chrono::steady_clock, as the reference's examples time
+// a frame, Examples/RGB-D/rgbd_tum.cc:92-108).
 int extract(const oracle_params& p, const Tables& t, const uint8_t* img, int w, int h,
-            size_t stride, oracle_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+            size_t stride, oracle_keypoint* kps, uint8_t* desc, int cap, int* n_out, double* stage_s = nullptr) {
+    typedef std::chrono::steady_clock Clock;
+    Clock::time_point mark = Clock::now();
+    auto lap = [&](int stage) {
+        if (!stage_s) return;
+        const Clock::time_point now = Clock::now();
+        stage_s[stage] += std::chrono::duration<double>(now - mark).count();
+        mark = now;
+    };
     *n_out = 0;
     if (w <= 0 || h <= 0 || !img) return 0;
     std::vector<Image> pyr;
     build_pyramid(t, img, w, h, stride, p.nlevels, pyr);
+    lap(0);
     std::vector<std::vector<oracle_keypoint>> all(p.nlevels);
     std::vector<Cand> cands;
     std::vector<int> sel;
@@ -602,6 +624,7 @@ int extract(const oracle_params& p, const Tables& t, const uint8_t* img, int w, 
         const int maxBorderX = L.w - EDGE_THRESHOLD + 3;
         const int maxBorderY = L.h - EDGE_THRESHOLD + 3;
         detect_cells(L.d.data(), L.w, L.h, L.w, p.ini_th_fast, p.min_th_fast, cands);
+        lap(1);
         // A level more than twice as tall as wide has round(width / height) = 0 initial nodes:
         // the reference (src/ORBextractor.cc:553-555) then divides by zero and indexes an
         // empty vector.  Reported as an error instead of reproduced.
@@ -623,10 +646,12 @@ int extract(const oracle_params& p, const Tables& t, const uint8_t* img, int w, 
             k.class_id = -1;
             all[level].push_back(k);
         }
+        lap(2);
     }
     for (int level = 0; level < p.nlevels; ++level)
         for (auto& k : all[level])
             k.angle = ic_angle(pyr[level].d.data(), pyr[level].w, cv_round(k.x), cv_round(k.y), t.umax);
+    lap(3);
 
     int total = 0;
     for (int level = 0; level < p.nlevels; ++level) total += (int)all[level].size();
@@ -638,6 +663,7 @@ int extract(const oracle_params& p, const Tables& t, const uint8_t* img, int w, 
         const Image& L = pyr[level];
         Image blurred(L.w, L.h);
         gaussian7(L.d.data(), L.w, L.h, L.w, blurred.d.data(), L.w, p.blur_variant);
+        lap(4);
         for (size_t i = 0; i < v.size(); i++)
             orb_descriptor(blurred.d.data(), L.w, cv_round(v[i].x), cv_round(v[i].y), v[i].angle,
                            desc + (size_t)(offset + i) * 32);
@@ -650,6 +676,7 @@ int extract(const oracle_params& p, const Tables& t, const uint8_t* img, int w, 
         }
         for (size_t i = 0; i < v.size(); i++) kps[offset + i] = v[i];
         offset += (int)v.size();
+        lap(5);
     }
     *n_out = total;
     return 0;
@@ -758,6 +785,21 @@ int oracle_extract(const oracle_params* p, const uint8_t* img, int w, int h, siz
                    oracle_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
     Tables t = make_tables(*p);
     return extract(*p, t, img, w, h, stride, kps, desc, cap, n_out);
+}
+
+int oracle_extract_stages(const oracle_params* p, const uint8_t* imgs, int nframes, int w, int h, size_t row_stride,
+                          size_t img_stride, double* stage_s) {
+    Tables t = make_tables(*p);
+    const int cap = p->nfeatures + 4096;
+    std::vector<oracle_keypoint> kps(cap);
+    std::vector<uint8_t> desc((size_t)cap * 32);
+    for (int i = 0; i < 6; i++) stage_s[i] = 0;
+    for (int f = 0; f < nframes; f++) {
+        int n = 0;
+        const int rc = extract(*p, t, imgs + (size_t)f * img_stride, w, h, row_stride, kps.data(), desc.data(), cap, &n, stage_s);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int oracle_extract_batch(const oracle_params* p, const uint8_t* imgs, int nframes, int w, int h,

@@ -77,6 +77,11 @@ void oracle_descriptor(const uint8_t* blurred, size_t stride, int x, int y, floa
 int oracle_extract(const oracle_params* p, const uint8_t* img, int w, int h, size_t stride,
                    oracle_keypoint* kps, uint8_t* desc, int cap, int* n_out);
 /* Frame-parallel batch over `threads` std::threads; same per-frame output layout. */
+/* Single-threaded extraction of nframes images with wall-clock seconds accumulated per stage:
+ * stage_s[6] = pyramid, FAST cells, quadtree, orientation, blur, descriptors. */
+int oracle_extract_stages(const oracle_params* p, const uint8_t* imgs, int nframes, int w, int h, size_t row_stride,
+                          size_t img_stride, double* stage_s);
+
 int oracle_extract_batch(const oracle_params* p, const uint8_t* imgs, int nframes, int w, int h,
                          size_t row_stride, size_t img_stride, oracle_keypoint* kps, uint8_t* desc,
                          int cap_per_frame, int* n_out, int threads);

@@ -183,6 +183,18 @@ def extract_batch(p, imgs, cap=None, threads=1):
     return kps, desc, n
 
 
+def extract_stages(p, imgs):
+    """Single-threaded extraction of a batch; seconds per stage as a dict."""
+    imgs = np.ascontiguousarray(imgs, np.uint8)
+    b, h, w = imgs.shape
+    t = np.zeros(6, np.float64)
+    rc = lib().oracle_extract_stages(C.byref(p), _p(imgs), b, w, h, C.c_size_t(imgs.strides[1]),
+                                     C.c_size_t(imgs.strides[0]), _p(t))
+    if rc:
+        raise RuntimeError("oracle_extract_stages failed rc=%d" % rc)
+    return dict(zip(("pyramid", "fast", "quadtree", "orientation", "blur", "describe"), t.tolist()))
+
+
 def compute_stereo_matches(p, img_left, img_right, kl, dl, kr, dr, mb, mbf):
     il = np.ascontiguousarray(img_left, np.uint8)
     ir = np.ascontiguousarray(img_right, np.uint8)
