@@ -741,9 +741,11 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-#define QT_THREADS 256  // measured on MI355X: 128 and 512 threads are slower, a single wave much slower
+// Threads per quadtree workgroup.  Measured on MI355X at 640x480 / 1000 features: 256 is best (128 and 512
+// slower, a single wave much slower); levels with thousands of nodes and 10^5 candidates want more.
 
 // Exclusive scan over the QT_THREADS threads of the block; *total = block sum.
+template <int QT_THREADS>
 __device__ __forceinline__ int block_excl_scan(int v, int* total, int* wsum) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int inc = wave_incl_scan(v);
@@ -794,6 +796,7 @@ __device__ __forceinline__ short4 child_box(short4 b, int q) {
 // sums so that positions, creation order and the stop rule equal those of the
 // sequential algorithm.  Node "addresses" in the size sort are modelled by
 // creation order (later created = greater).
+template <int QT_THREADS>
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __restrict__ cellCount,
                                                    const u32* __restrict__ slots, u32* keyPacked,
                                                    u16* keyNode, u32* sel, int* selCount,
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         const int c = base + tid;
         const int cN = c < LG.nCells ? (int)cc[c] : 0;
         int tot;
-        const int off = block_excl_scan(cN, &tot, S.wsum);
+        const int off = block_excl_scan<QT_THREADS>(cN, &tot, S.wsum);
         for (int k = 0; k < cN; k++) kp[nkeys + off + k] = sl[(i64)c * LG.cellCap + k];
         nkeys += tot;
     }
@@ -898,9 +901,21 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         const int nxt = cur ^ 1;
         for (int i = tid; i < L * 4; i += QT_THREADS) childCnt[i] = 0;
         __syncthreads();
-        for (int k = tid; k < nkeys; k += QT_THREADS) {
-            const int nd = kn[k];
-            if (ccnt[nd] > 1) atomicAdd(&childCnt[nd * 4 + child_quadrant(kp[k], cb[nd])], 1u);
+        // four keys per trip: the loads of a trip are issued together, so a thread waits for
+        // memory once per four keys
+        for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
+            int nd[4];
+            u32 key[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = min(k0 + j * QT_THREADS, nkeys - 1);
+                nd[j] = kn[k];
+                key[j] = kp[k];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (k0 + j * QT_THREADS < nkeys && ccnt[nd[j]] > 1)
+                    atomicAdd(&childCnt[nd[j] * 4 + child_quadrant(key[j], cb[nd[j]])], 1u);
         }
         __syncthreads();
         // processing order of expandable nodes
@@ -910,7 +925,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 const int i = base + tid;
                 const int e = (i < L && ccnt[i] > 1) ? 1 : 0;
                 int tot;
-                const int off = block_excl_scan(e, &tot, S.wsum);
+                const int off = block_excl_scan<QT_THREADS>(e, &tot, S.wsum);
                 if (i < L) rankOf[i] = e ? (u16)(C + off) : (u16)0xFFFF;
                 C += tot;
             }
@@ -934,7 +949,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 const int i = base + tid;
                 const int e = (i < L && ccnt[i] > 1) ? 1 : 0;
                 int tot;
-                block_excl_scan(e, &tot, S.wsum);
+                block_excl_scan<QT_THREADS>(e, &tot, S.wsum);
                 C += tot;
             }
         }
@@ -956,7 +971,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
             const int j = base + tid;
             const int m = j < C ? (int)mOf[nodeOfRank[j]] : 0;
             int tot;
-            const int off = block_excl_scan(m, &tot, S.wsum);
+            const int off = block_excl_scan<QT_THREADS>(m, &tot, S.wsum);
             int lt = 0;
             if (j < C) {
                 gpre[j] = (u32)(run + off);
@@ -964,7 +979,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 lt = (L + (run + off + m) - (j + 1)) < N ? 1 : 0;
             }
             int tl;
-            block_excl_scan(lt, &tl, S.wsum);
+            block_excl_scan<QT_THREADS>(lt, &tl, S.wsum);
             below += tl;
             run += tot;
         }
@@ -982,7 +997,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
             const int i = base + tid;
             const int s = (i < L && (rankOf[i] == 0xFFFF || rankOf[i] >= nproc)) ? 1 : 0;
             int tot;
-            const int off = block_excl_scan(s, &tot, S.wsum);
+            const int off = block_excl_scan<QT_THREADS>(s, &tot, S.wsum);
             if (s) {
                 const int np = tnew + stay + off;
                 moved[i] = (u16)np;
@@ -1018,17 +1033,30 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         }
         {
             int tot;
-            block_excl_scan(expand, &tot, S.wsum);
+            block_excl_scan<QT_THREADS>(expand, &tot, S.wsum);
             expand = tot;
         }
         __syncthreads();
-        for (int k = tid; k < nkeys; k += QT_THREADS) {
-            const int nd = kn[k];
-            const u16 r = rankOf[nd];
-            if (r != 0xFFFF && r < nproc)
-                kn[k] = newId[nd * 4 + child_quadrant(kp[k], cb[nd])];
-            else
-                kn[k] = moved[nd];
+        for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
+            int nd[4];
+            u32 key[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = min(k0 + j * QT_THREADS, nkeys - 1);
+                nd[j] = kn[k];
+                key[j] = kp[k];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = k0 + j * QT_THREADS;
+                if (k < nkeys) {
+                    const u16 r = rankOf[nd[j]];
+                    if (r != 0xFFFF && r < nproc)
+                        kn[k] = newId[nd[j] * 4 + child_quadrant(key[j], cb[nd[j]])];
+                    else
+                        kn[k] = moved[nd[j]];
+                }
+            }
         }
         nextSeq += (u32)tnew;
         const int newL = tnew + stay;
@@ -1054,9 +1082,20 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     u64* best = (u64*)childCnt;
     for (int i = tid; i < L; i += QT_THREADS) best[i] = 0;
     __syncthreads();
-    for (int k = tid; k < nkeys; k += QT_THREADS) {
-        const u64 v = ((u64)ORBX_PR(kp[k]) << 32) | (u64)(0xFFFFFFFFu - (u32)k);
-        atomicMax(&best[kn[k]], v);
+    for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
+        int nd[4];
+        u32 key[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = min(k0 + j * QT_THREADS, nkeys - 1);
+            nd[j] = kn[k];
+            key[j] = kp[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j * QT_THREADS;
+            if (k < nkeys) atomicMax(&best[nd[j]], ((u64)ORBX_PR(key[j]) << 32) | (u64)(0xFFFFFFFFu - (u32)k));
+        }
     }
     __syncthreads();
     for (int i = tid; i < L; i += QT_THREADS) {
@@ -1375,6 +1414,7 @@ struct orbx_handle {
     Geom g;
     bool geomValid = false;
     size_t qtLds = 0;
+    int qtThreads = 256;
     ResizeTap* dTaps = nullptr;  // x taps then y taps for each level >= 1
     FastCell* dCells = nullptr;  // one record per FAST cell, all levels
     size_t cellsCap = 0;
@@ -1595,8 +1635,18 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         return ORBX_ERR_UNSUPPORTED;
     }
     h->qtLds = maxLds;
-    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)maxLds));
+    {
+        // one workgroup walks all candidates of a level several times and ranks its nodes: levels with
+        // thousands of nodes (4K frames with 10^4 features) want more threads than VGA levels do
+        int maxQuota = 0;
+        for (int l = 0; l < g.nlevels; l++) maxQuota = std::max(maxQuota, g.lv[l].quota);
+        h->qtThreads = maxQuota >= 1400 ? 1024 : maxQuota >= 700 ? 512 : 256;
+    }
+    if (const char* e = getenv("ORBX_QT_THREADS")) h->qtThreads = atoi(e);
+    if (h->qtThreads != 256 && h->qtThreads != 512 && h->qtThreads != 1024) h->qtThreads = 256;
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
 
     // resize taps (cv::resize INTER_LINEAR, 8-bit, 11-bit fixed-point weights)
     std::vector<ResizeTap> taps;
@@ -1887,8 +1937,9 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     }
     {
         StageTimer t(h, ORBX_STAGE_QUADTREE);
-        dim3 grid(g.nlevels, n, 1), block(QT_THREADS, 1, 1);
-        hipLaunchKernelGGL(k_quadtree, grid, block, h->qtLds, st, g, (const u32*)h->dCellCount,
+        dim3 grid(g.nlevels, n, 1), block(h->qtThreads, 1, 1);
+        auto kq = h->qtThreads == 1024 ? k_quadtree<1024> : h->qtThreads == 512 ? k_quadtree<512> : k_quadtree<256>;
+        hipLaunchKernelGGL(kq, grid, block, h->qtLds, st, g, (const u32*)h->dCellCount,
                            (const u32*)h->dSlots, h->dKeyPacked, h->dKeyNode, h->dSel, h->dSelCount, h->dErr);
     }
     if (fork) ORBX_HIP_CHECK(hipStreamWaitEvent(st, h->evBlur, 0));
