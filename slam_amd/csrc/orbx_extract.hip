@@ -498,7 +498,7 @@ __device__ __forceinline__ int fast_strength(const int* d) {
 
 // floor(i / d) for i, d < 65536 with magic = floor(2^32 / d) + 1 (d >= 2).
 __device__ __forceinline__ u32 fastdiv(u32 i, u32 d, u32 magic) { return d == 1 ? i : __umulhi(i, magic); }
-__device__ __forceinline__ u32 div_magic(u32 d) { return d <= 1 ? 0u : (u32)(0x100000000ull / d) + 1u; }
+__host__ __device__ __forceinline__ u32 div_magic(u32 d) { return d <= 1 ? 0u : (u32)(0x100000000ull / d) + 1u; }
 
 // Per-cell constants, computed on the host when the geometry is set up so that a wave
 // starts without divisions or level searches.
@@ -1210,6 +1210,12 @@ __global__ void k_debug_atan2(const float* y, const float* x, float* out, int n)
 }
 
 #define DESC_KPW 8  // keypoints per wave
+#define DESC_R 18            // window radius of the steered tests
+#define DESC_ROW_DW 10       // 32-bit words per window row (37 bytes + up to 3 of alignment)
+#define DESC_WIN_DW 384      // window slots in LDS: 37 * 10 = 370 used, six loads of 64 lanes
+#ifndef DESC_BATCH
+#define DESC_BATCH 8         // windows staged at a time per wave
+#endif
 
 __device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float readlane_f(float v, int lane) {
@@ -1225,14 +1231,25 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 //      lanes 8j..8j+7, where fastAtan2 and the steering sine/cosine are evaluated once for
 //      all keypoints;
 //   C. per keypoint: 256 steered tests on the blurred level, one bit per lane and round,
-//      gathered with wave ballots.
+//      gathered with wave ballots.  The rotated test points stay within 18 pixels of the keypoint
+//      (the pattern's largest radius is 18.38), so the 37 x 40-byte window around each keypoint is
+//      copied to LDS with six row-coalesced direct-to-LDS loads and the 512 byte gathers of a
+//      keypoint hit LDS: gathering from global memory costs a wave up to 64 cache-line
+//      lookups per load instruction, which bounded this kernel.
 __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8* __restrict__ pyr,
                                                    const u8* __restrict__ blur,
                                                    const u32* __restrict__ sel,
                                                    const int* __restrict__ selCount,
                                                    orbx_keypoint* kps, u8* desc, int cap, int* nOut,
-                                                   int* errFlag) {
-    const int f = blockIdx.x;  // frame first: one XCD per frame
+                                                   int* errFlag, int nFrames, int nChunks, u32 chunkMagic) {
+    // Workgroups go to the 8 XCDs round-robin by linear id.  XCD x takes frames x, x + 8, ... and
+    // walks through all keypoint chunks of one frame before the next, so the patches and windows of
+    // a frame, which overlap heavily, are fetched into that XCD's L2 once instead of once per chunk.
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int fq = (int)fastdiv((u32)seq, (u32)nChunks, chunkMagic);
+    const int f = fq * 8 + xcd;
+    const int chunk = seq - fq * nChunks;
+    if (f >= nFrames) return;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int* sc = selCount + (i64)f * ORBX_MAX_LEVELS;
@@ -1241,7 +1258,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
 #pragma unroll
     for (int k = 0; k < ORBX_MAX_LEVELS; k++) cum[k + 1] = cum[k] + (k < g.nlevels ? sc[k] : 0);
     const int total = min(cum[ORBX_MAX_LEVELS], cap);
-    const int sBase = (blockIdx.y * 4 + wv) * DESC_KPW;
+    const int sBase = (chunk * 4 + wv) * DESC_KPW;
     if (sBase == 0 && lane == 0) {
         nOut[f] = total;
         if (cum[ORBX_MAX_LEVELS] > cap) *errFlag = 2;
@@ -1286,6 +1303,31 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
         myR = ORBX_PR(key);
     }
 
+    __shared__ u32 window[4][DESC_BATCH][DESC_WIN_DW];
+    u32 winOff[6];  // this lane's six window words: byte offset from the window's corner = row * pitch + 4 * word
+    u32 winRow[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int i = min(k * 64 + lane, DESC_ROW_DW * (2 * DESC_R + 1) - 1);
+        const int row = (int)__umulhi((u32)i, div_magic(DESC_ROW_DW));
+        winRow[k] = (u32)row;
+        winOff[k] = (u32)(4 * (i - row * DESC_ROW_DW));
+    }
+    auto issue_windows = [&](int j0) {
+#pragma unroll
+        for (int jj = 0; jj < DESC_BATCH; jj++) {
+            const int j = j0 + jj;
+            const int l = readlane_i(myL, j), x = readlane_i(myX, j), y = readlane_i(myY, j);
+            const u32 blurPitch = (u32)g.lv[l].blurPitch;
+            // top-left corner of the window: a wave-uniform base plus a non-negative 32-bit lane offset
+            const u8* wb = blur + (i64)f * g.blurFrameBytes + g.lv[l].blurOff + (i64)(y - DESC_R) * blurPitch + ((x - DESC_R) & ~3);
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(wb + (size_t)mad24(winRow[k], blurPitch, winOff[k])),
+                    (__attribute__((address_space(3))) void*)&window[wv][jj][k * 64], 4, 0, 0);
+        }
+    };
     // A: moments
     int V[2 * DESC_KPW];
     {
@@ -1294,14 +1336,15 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
         for (int j = 0; j < DESC_KPW; j++) {
             const int l = readlane_i(myL, j), x = readlane_i(myX, j), y = readlane_i(myY, j);
             const ImgRef im = level_image(g, l, img0, pyr);
-            const u8* center = im.base + (i64)f * im.frameStride + (i64)y * im.pitch + x;
+            // corner of the 31 x 32 patch: a wave-uniform base plus a non-negative 32-bit lane offset
+            const u8* corner = im.base + (i64)f * im.frameStride + (i64)(y - 15) * im.pitch + (x - 16);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int slot = min(lane + 64 * i, 247);
-                const int v = (slot >> 3) - 15, u0 = (slot & 7) * 4 - 16;
-                __builtin_memcpy(&px[j][i], center + v * im.pitch + u0, 4);
+                const u32 slot = (u32)min(lane + 64 * i, 247);
+                __builtin_memcpy(&px[j][i], corner + (size_t)mad24(slot >> 3, (u32)im.pitch, (slot & 7) * 4), 4);
             }
         }
+        issue_windows(0);  // the first windows travel while the moments are computed
 #pragma unroll
         for (int j = 0; j < DESC_KPW; j++) {
             int m10 = 0, m01 = 0;
@@ -1342,44 +1385,69 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
     steer_sincos(__fmul_rn(angleV, factorPI), &bV, &aV);
 
     // C: descriptors and keypoint records
+#pragma unroll 1
+    for (int j0 = 0; j0 < DESC_KPW; j0 += DESC_BATCH) {
+        if (sBase + j0 >= total) break;
+        if (j0 > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous batch has been read
+            issue_windows(j0);
+        }
+        // direct-to-LDS loads are not tracked as LDS writes by the compiler: wait for them here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 2
-    for (int j = 0; j < DESC_KPW; j++) {
-        const int s = sBase + j;
-        if (s >= total) break;
-        const int l = readlane_i(myL, j), x = readlane_i(myX, j), y = readlane_i(myY, j), resp = readlane_i(myR, j);
-        const float a = readlane_f(aV, 8 * j), b = readlane_f(bV, 8 * j), angle = readlane_f(angleV, 8 * j);
-        const int blurPitch = g.lv[l].blurPitch;
-        const u8* bc = blur + (i64)f * g.blurFrameBytes + g.lv[l].blurOff + (i64)y * blurPitch + x;
-        u32 word = 0;  // lane k < 8 ends up holding descriptor bytes 4k..4k+3
+        for (int jj = 0; jj < DESC_BATCH; jj++) {
+            const int j = j0 + jj;
+            const int s = sBase + j;
+            if (s >= total) break;
+            const int l = readlane_i(myL, j), x = readlane_i(myX, j), y = readlane_i(myY, j), resp = readlane_i(myR, j);
+            const float a = readlane_f(aV, 8 * j), b = readlane_f(bV, 8 * j), angle = readlane_f(angleV, 8 * j);
+            // Byte address of the keypoint in its LDS window.  Rounding to nearest-even is done by adding
+            // 1.5 * 2^23: the sum's bit pattern is 0x4B400000 + round(v) for |v| < 2^22, and a 24-bit
+            // multiply-add on the patterns gives 40 * row + column plus a constant folded into the base.
+            const u32 MAGIC = 0x4B400000u;
+            const u32 bc = (u32)__builtin_amdgcn_readfirstlane(
+                (int)((u32)(size_t)(const __attribute__((address_space(3))) u8*)&window[wv][jj][0] +
+                      DESC_R * (4 * DESC_ROW_DW) + DESC_R + ((x - DESC_R) & 3) -
+                      ((MAGIC & 0xFFFFFFu) * (4 * DESC_ROW_DW) + MAGIC)));
+            u32 t0[4], t1[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)));
-            const int t0 = bc[r0 * blurPitch + c0];
-            const int t1 = bc[r1 * blurPitch + c1];
-            const u64 bits = __ballot(t0 < t1);
-            if (lane == 2 * r) word = (u32)bits;
-            if (lane == 2 * r + 1) word = (u32)(bits >> 32);
+            for (int r = 0; r < 4; r++) {
+                const float fr0 = __fadd_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)), 12582912.f);
+                const float fc0 = __fadd_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)), 12582912.f);
+                const float fr1 = __fadd_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)), 12582912.f);
+                const float fc1 = __fadd_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)), 12582912.f);
+                const u32 a0 = mad24(__float_as_uint(fr0), 4 * DESC_ROW_DW, __float_as_uint(fc0)) + bc;
+                const u32 a1 = mad24(__float_as_uint(fr1), 4 * DESC_ROW_DW, __float_as_uint(fc1)) + bc;
+                t0[r] = *(const __attribute__((address_space(3))) u8*)(size_t)a0;
+                t1[r] = *(const __attribute__((address_space(3))) u8*)(size_t)a1;
+            }
+            u32 word = 0;  // lane k < 8 ends up holding descriptor bytes 4k..4k+3
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const u64 bits = __ballot(t0[r] < t1[r]);
+                // (a VALU compare result read by v_writelane right away returns stale data, so the
+                // selection stays on conditional moves)
+                word = lane == 2 * r ? (u32)bits : word;
+                word = lane == 2 * r + 1 ? (u32)(bits >> 32) : word;
+            }
+            const i64 o = (i64)f * cap + s;
+            if (lane < 8) ((u32*)(desc + o * 32))[lane] = word;
+            // the 7 dwords of the 28-byte keypoint, one per lane
+            float kx = (float)x, ky = (float)y;
+            const float scale = g.lv[l].scale, kpSize = g.lv[l].kpSize;
+            if (l != 0) {
+                kx = __fmul_rn(kx, scale);
+                ky = __fmul_rn(ky, scale);
+            }
+            u32 kv = __float_as_uint(kx);
+            kv = lane == 1 ? __float_as_uint(ky) : kv;
+            kv = lane == 2 ? __float_as_uint(kpSize) : kv;
+            kv = lane == 3 ? __float_as_uint(angle) : kv;
+            kv = lane == 4 ? __float_as_uint((float)resp) : kv;
+            kv = lane == 5 ? (u32)l : kv;
+            kv = lane == 6 ? 0xFFFFFFFFu : kv;
+            if (lane < 7) ((u32*)(kps + o))[lane] = kv;
         }
-        const i64 o = (i64)f * cap + s;
-        if (lane < 8) ((u32*)(desc + o * 32))[lane] = word;
-        // the 7 dwords of the 28-byte keypoint, one per lane
-        float kx = (float)x, ky = (float)y;
-        const float scale = g.lv[l].scale, kpSize = g.lv[l].kpSize;
-        if (l != 0) {
-            kx = __fmul_rn(kx, scale);
-            ky = __fmul_rn(ky, scale);
-        }
-        u32 kv = __float_as_uint(kx);
-        kv = lane == 1 ? __float_as_uint(ky) : kv;
-        kv = lane == 2 ? __float_as_uint(kpSize) : kv;
-        kv = lane == 3 ? __float_as_uint(angle) : kv;
-        kv = lane == 4 ? __float_as_uint((float)resp) : kv;
-        kv = lane == 5 ? (u32)l : kv;
-        kv = lane == 6 ? 0xFFFFFFFFu : kv;
-        if (lane < 7) ((u32*)(kps + o))[lane] = kv;
     }
 }
 
@@ -1945,9 +2013,11 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     if (fork) ORBX_HIP_CHECK(hipStreamWaitEvent(st, h->evBlur, 0));
     {
         StageTimer t(h, ORBX_STAGE_DESCRIBE);
-        dim3 grid(n, (std::min(cap, g.totalSel) + 4 * DESC_KPW - 1) / (4 * DESC_KPW), 1), block(256, 1, 1);
+        const int nChunks = (std::min(cap, g.totalSel) + 4 * DESC_KPW - 1) / (4 * DESC_KPW);
+        dim3 grid(8 * ((n + 7) / 8) * nChunks, 1, 1), block(256, 1, 1);
         hipLaunchKernelGGL(k_describe, grid, block, 0, st, g, img0, (const u8*)h->dPyr, (const u8*)h->dBlur,
-                           (const u32*)h->dSel, (const int*)h->dSelCount, dKps, dDesc, cap, dN, h->dErr);
+                           (const u32*)h->dSel, (const int*)h->dSelCount, dKps, dDesc, cap, dN, h->dErr, n, nChunks,
+                           div_magic((u32)nChunks));
     }
     ORBX_HIP_CHECK(hipGetLastError());
     return ORBX_OK;

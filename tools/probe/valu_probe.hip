@@ -11,6 +11,9 @@ __global__ __launch_bounds__(256) void k_op(unsigned* out, int iters, unsigned s
 #pragma unroll
     for (int i = 0; i < 16; i++) v[i] = threadIdx.x * 2654435761u + i * seed;
     const unsigned c = seed | 1u;
+    const unsigned long long mask = 0x5555aaaa3333ccccull ^ seed;
+    unsigned sacc = 0;
+    if (OP == 12) asm volatile("s_mov_b64 vcc, %0" : : "s"(mask) : "vcc");
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -36,12 +39,27 @@ __global__ __launch_bounds__(256) void k_op(unsigned* out, int iters, unsigned s
             if (OP == 19) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
             if (OP == 20) asm volatile("v_cmp_gt_i32 vcc, %0, %1" : : "v"(v[i]), "v"(c) : "vcc");
             if (OP == 21) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(*(unsigned long long*)&v[i & ~1]) : "v"(*(unsigned long long*)&v[(i & ~1)]));
+            if (OP == 22) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[i]) : "v"(c), "s"(mask));
+            if (OP == 23) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 24) asm volatile("v_rndne_f32 %0, %0" : "+v"(v[i]));
+            if (OP == 25) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(v[i]));
+            if (OP == 26) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 27) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 28) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(unsigned long long*)&v[i & ~1]) : "v"(*(unsigned long long*)&v[(i & ~1)]));
+            if (OP == 29) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[i]));
+            if (OP == 30) asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(v[i]) : "v"(c & 0xfcu));
+            if (OP == 31) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(c) : "vcc");
+            if (OP == 32) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sacc) : "v"(v[i]));
+            if (OP == 33) asm volatile("v_add3_u32 %0, %0, %1, %0" : "+v"(v[i]) : "v"(c));
+            if (OP == 34) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(v[i]));
+            if (OP == 35) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 36) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(v[i]));
         }
     }
     unsigned acc = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc ^= v[i];
-    if (acc == 0x12345u) out[0] = acc;
+    if (acc == 0x12345u) out[0] = acc + sacc;
 }
 
 template <int OP>
@@ -60,7 +78,7 @@ void run(const char* name, unsigned* out, double clockGHz) {
     CK(hipEventElapsedTime(&ms, a, b));
     const double waveInstr = (double)blocks * 4 * iters * 16;
     const double perSimdPerSec = waveInstr / 1024.0 / (ms * 1e-3);
-    printf("%-18s %.3f ms  %.2f cycles per wave64 instruction per SIMD at %.2f GHz\n", name, ms, clockGHz * 1e9 / perSimdPerSec, clockGHz);
+    printf("%-26s %.3f ms  %.2f cycles per wave64 instruction per SIMD at %.2f GHz\n", name, ms, clockGHz * 1e9 / perSimdPerSec, clockGHz);
 }
 
 int main() {
@@ -91,5 +109,20 @@ int main() {
     run<19>("v_sub_u32", out, ghz);
     run<20>("v_cmp_gt_i32", out, ghz);
     run<21>("v_pk_fma_f32", out, ghz);
+    run<22>("v_cndmask_b32 (sgpr mask)", out, ghz);
+    run<23>("v_bfi_b32", out, ghz);
+    run<24>("v_rndne_f32", out, ghz);
+    run<25>("v_cvt_i32_f32", out, ghz);
+    run<26>("v_mul_f32", out, ghz);
+    run<27>("v_add_f32", out, ghz);
+    run<28>("v_pk_mul_f32", out, ghz);
+    run<29>("v_mov_b32 dpp row_shr", out, ghz);
+    run<30>("ds_bpermute_b32 + wait", out, ghz);
+    run<31>("v_cmp + v_cndmask (pair)", out, ghz);
+    run<32>("v_readlane_b32", out, ghz);
+    run<33>("v_add3_u32", out, ghz);
+    run<34>("v_lshlrev_b32", out, ghz);
+    run<35>("v_and_b32", out, ghz);
+    run<36>("v_cvt_f32_i32", out, ghz);
     return 0;
 }
