@@ -152,9 +152,9 @@ __global__ __launch_bounds__(256) void k_resize(ImgRef src, u8* dst, int dPitch,
 __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, int sh, u8* dst, int dPitch, i64 dFrame,
                                                         int dw, int dh, const ResizeTap* __restrict__ xt,
                                                         const ResizeTap* __restrict__ yt,
-                                                        const ResizeTap* __restrict__ st) {
+                                                        const ResizeTap* __restrict__ st, int bandRows) {
     const int G = (dw + 3) >> 2;
-    const int nb = (dh + RESIZE_BH - 1) / RESIZE_BH;
+    const int nb = (dh + bandRows - 1) / bandRows;
     // blockIdx.x is the frame: blocks are dealt round-robin over the 8 XCDs, so with a batch
     // that is a multiple of 8 all blocks of one frame share an XCD (and its L2) and the rows
     // two neighbouring bands both read are fetched from HBM once.
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, 
     const u8* sbase = src.base + (i64)f * src.frameStride;
     const u32 sPitch = (u32)src.pitch, dPitchU = (u32)dPitch;
     u8* dbase = dst + (i64)f * dFrame + 4 * gx;
-    const int y0 = band * RESIZE_BH, y1 = min(y0 + RESIZE_BH, dh);
+    const int y0 = band * bandRows, y1 = min(y0 + bandRows, dh);
 
     struct Raw {
         u32 a, b, c;
@@ -206,29 +206,26 @@ __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, 
     int s = yt[y0].i0;                // first source row of the band
     const int sLast = yt[y1 - 1].i1;  // last one
     u32 prev[4] = {0, 0, 0, 0}, cur[4];
-    Raw rawCur[RESIZE_PF];
-    uint4 tabCur[RESIZE_PF];
-#pragma unroll
-    for (int k = 0; k < RESIZE_PF; k++) {
-        rawCur[k] = fetch(s + k);
-        tabCur[k] = *(const uint4*)(st + 2 * min(s + k, sh - 1));
-    }
-    while (s <= sLast) {
-        Raw rawNxt[RESIZE_PF];
-        uint4 tabNxt[RESIZE_PF];
+    struct Group {
+        Raw raw[RESIZE_PF];
+        uint4 tab[RESIZE_PF];
+    };
+    auto load_group = [&](Group& g, int s0) {
 #pragma unroll
         for (int k = 0; k < RESIZE_PF; k++) {
-            rawNxt[k] = fetch(s + RESIZE_PF + k);
-            tabNxt[k] = *(const uint4*)(st + 2 * min(s + RESIZE_PF + k, sh - 1));
+            g.raw[k] = fetch(s0 + k);
+            g.tab[k] = *(const uint4*)(st + 2 * min(s0 + k, sh - 1));
         }
+    };
+    auto run_group = [&](const Group& g, int s0) {
 #pragma unroll
         for (int k = 0; k < RESIZE_PF; k++) {
-            hsum(rawCur[k], cur);
+            hsum(g.raw[k], cur);
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                const u32 w0 = e == 0 ? tabCur[k].x : tabCur[k].z, w1 = e == 0 ? tabCur[k].y : tabCur[k].w;
+                const u32 w0 = e == 0 ? g.tab[k].x : g.tab[k].z, w1 = e == 0 ? g.tab[k].y : g.tab[k].w;
                 const int y = (int)(w0 & 0xffffu);
-                if (y >= y0 && y < y1 && s + k <= sLast) {
+                if (y >= y0 && y < y1 && s0 + k <= sLast) {
                     const bool same = (w0 >> 16) != 0;
                     // weights are 0..2048 and the shifted sums < 2^15: (b * t) >> 16 = mulhi(b << 16, t)
                     const u32 b0 = w1 << 16, b1 = w1 & 0xffff0000u;
@@ -245,12 +242,21 @@ __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, 
 #pragma unroll
             for (int j = 0; j < 4; j++) prev[j] = cur[j];
         }
+    };
+    // Two register sets used alternately: a set is refilled right after its rows have been consumed and
+    // is not touched again until the other set has been worked through, so its loads have a whole
+    // group of rows to land (copying "next" into "current" would wait for them at the end of every group).
+    Group ga, gb;
+    load_group(ga, s);
+    while (true) {
+        load_group(gb, s + RESIZE_PF);
+        run_group(ga, s);
         s += RESIZE_PF;
-#pragma unroll
-        for (int k = 0; k < RESIZE_PF; k++) {
-            rawCur[k] = rawNxt[k];
-            tabCur[k] = tabNxt[k];
-        }
+        if (s > sLast) break;
+        load_group(ga, s + RESIZE_PF);
+        run_group(gb, s);
+        s += RESIZE_PF;
+        if (s > sLast) break;
     }
 }
 
@@ -427,20 +433,16 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
 #pragma unroll
         for (int k = 0; k < 4; k++) lastHs[k] = h0[k];
     }
-    for (int yb = y0; yb < yEnd; yb += 7) {
-        Raw nxt[7];
-        if (yb + 7 < yEnd) {
+    auto load_group = [&](Raw* grp, int yFirst) {
 #pragma unroll
-            for (int i = 0; i < 7; i++) nxt[i] = fetch(yb + 10 + i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 7; i++) nxt[i] = cur[i];
-        }
+        for (int i = 0; i < 7; i++) grp[i] = fetch(yFirst + i);
+    };
+    auto run_group = [&](const Raw* grp, int yb) {
 #pragma unroll
         for (int ph = 0; ph < 7; ph++) {
             const int y = yb + ph;
             u32 hs[4];
-            hrow(cur[ph], hs);
+            hrow(grp[ph], hs);
             // The rounded sum is < 2^25; clamped to 0xFFFFFF its byte 2 is the saturated output pixel.
             u32 sv[4];
 #pragma unroll
@@ -459,8 +461,20 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
             const u32 out = lo | hi;
             if (y < yEnd) *(u32*)(dst + mul24((u32)y, dstPitch)) = out;
         }
-#pragma unroll
-        for (int i = 0; i < 7; i++) cur[i] = nxt[i];
+    };
+    // Two register sets used alternately (no copy from "next" to "current", which would wait for the
+    // loads at the end of every group): a set is refilled right after its rows have been filtered.
+    Raw other[7];
+    int yb = y0;
+    while (true) {
+        if (yb + 7 < yEnd) load_group(other, yb + 10);
+        run_group(cur, yb);
+        yb += 7;
+        if (yb >= yEnd) break;
+        if (yb + 7 < yEnd) load_group(cur, yb + 10);
+        run_group(other, yb);
+        yb += 7;
+        if (yb >= yEnd) break;
     }
 }
 
@@ -1947,11 +1961,29 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             const LevelGeom& L = g.lv[l];
             const bool srcAligned = ((((uintptr_t)src.base) | (uintptr_t)src.pitch | (uintptr_t)src.frameStride) & 3u) == 0;
             if (srcAligned && h->resizeStreamOk[l]) {
-                const int items = ((L.w + 3) / 4) * ((L.h + RESIZE_BH - 1) / RESIZE_BH);
+                // destination rows per band: 32 where that still gives the launch enough waves, fewer
+                // on the small levels (a band re-reads about two source rows of its neighbour)
+                int bandRows = RESIZE_BH;
+                {
+                    static int forced[ORBX_MAX_LEVELS] = {-1};
+                    if (forced[0] == -1) {
+                        for (int i = 0; i < ORBX_MAX_LEVELS; i++) forced[i] = 0;
+                        if (const char* e = getenv("ORBX_RESIZE_BH")) {
+                            int i = 1;
+                            for (const char* q = e; *q && i < ORBX_MAX_LEVELS; i++) {
+                                forced[i] = atoi(q);
+                                while (*q && *q != ',') q++;
+                                if (*q == ',') q++;
+                            }
+                        }
+                    }
+                    if (forced[l] > 0) bandRows = forced[l];
+                }
+                const int items = ((L.w + 3) / 4) * ((L.h + bandRows - 1) / bandRows);
                 dim3 grid(n, (items + 255) / 256, 1), block(256, 1, 1);
                 hipLaunchKernelGGL(k_resize_stream, grid, block, 0, st, src, src.pitch / 4 - 1, g.lv[l - 1].h, h->dPyr + L.pyrOff,
                                    L.pyrPitch, g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l],
-                                   h->dTaps + h->tapYOff[l], h->dTaps + h->tapSOff[l]);
+                                   h->dTaps + h->tapYOff[l], h->dTaps + h->tapSOff[l], bandRows);
             } else {
                 dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, n), block(64, 4, 1);
                 hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, h->dPyr + L.pyrOff, L.pyrPitch,

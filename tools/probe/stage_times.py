@@ -21,6 +21,7 @@ ap.add_argument("--nf", type=int, default=1000)
 ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--chunk", type=int, default=512)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--serial-only", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 ex = ORBextractor(a.nf, 1.2, 8, 20, 7, max_width=a.w, max_height=a.h, max_batch=min(a.chunk, a.frames))
@@ -34,7 +35,7 @@ for f0 in range(0, a.frames, 16):
 k = torch.zeros(a.frames * cap * 28, dtype=torch.uint8, device=dev)
 d = torch.zeros(a.frames * cap * 32, dtype=torch.uint8, device=dev)
 n = torch.zeros(a.frames, dtype=torch.int32, device=dev)
-for overlap in (False, True):
+for overlap in ((False,) if a.serial_only else (False, True)):
     ex.set_overlap(overlap)
     ex.extract_batch_device(buf[:, :, :a.w], k, d, n, cap)
     torch.cuda.synchronize()
