@@ -1527,6 +1527,8 @@ struct orbx_handle {
     // staging for host-memory calls
     u8* dImgStage = nullptr;
     size_t imgStageCap = 0;
+    u8* dRawStage = nullptr;  // host rows as they are (any row stride), before the repack to the staged pitch
+    size_t rawStageCap = 0;
     orbx_keypoint* dKpStage = nullptr;
     u8* dDescStage = nullptr;
     int* dNStage = nullptr;
@@ -2140,7 +2142,7 @@ void orbx_destroy(orbx_handle* h) {
         if (P.evDone) (void)hipEventDestroy(P.evDone);
     }
     if (h->evStart) (void)hipEventDestroy(h->evStart);
-    free_dev(h->dErr); free_dev(h->dTaps); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dKpStage);
+    free_dev(h->dErr); free_dev(h->dTaps); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dRawStage); free_dev(h->dKpStage);
     free_dev(h->dDescStage); free_dev(h->dNStage);
     for (int s = 0; s < ORBX_STAGE_COUNT; s++)
         for (auto& e : h->prof.ev[s]) {
@@ -2257,17 +2259,38 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
         ImgRef img0;
         if (mem_space == ORBX_MEM_HOST) {
             // staged rows are padded to 64 bytes so that every kernel can use aligned word loads
+            // A pitched copy from pageable host memory is issued row by row and is orders of magnitude
+            // slower than a linear one, so host rows always travel as linear copies: straight into the
+            // staging buffer when they already have its pitch, otherwise into a raw buffer that a
+            // device-side pitched copy repacks.
             const size_t sp = (size_t)align_up(w, 64);
-            if (img_stride == row_stride * (size_t)hh) {
-                ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage, sp, imgs + (size_t)f0 * img_stride, row_stride,
-                                                (size_t)w, (size_t)hh * n, hipMemcpyHostToDevice, h->stream));
-            } else {
-                // frames are not back to back in host memory: copy one by one
-                for (int f = 0; f < n; f++)
-                    ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage + (size_t)f * sp * hh, sp,
-                                                    imgs + (size_t)(f0 + f) * img_stride, row_stride, (size_t)w,
-                                                    (size_t)hh, hipMemcpyHostToDevice, h->stream));
+            const bool packed = img_stride == row_stride * (size_t)hh;
+            const bool direct = row_stride == sp;
+            u8* land = h->dImgStage;
+            if (!direct) {
+                const size_t rawBytes = (size_t)n * row_stride * hh;
+                if (rawBytes > h->rawStageCap) {
+                    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+                    free_dev(h->dRawStage);
+                    h->dRawStage = nullptr;
+                    h->rawStageCap = 0;
+                    ORBX_HIP_CHECK(hipMalloc((void**)&h->dRawStage, (size_t)chunk * row_stride * hh + 256));
+                    h->rawStageCap = (size_t)chunk * row_stride * hh;
+                }
+                land = h->dRawStage;
             }
+            const size_t frameBytes = row_stride * (size_t)(hh - 1) + (size_t)w;  // the last row may end at w
+            if (packed) {
+                ORBX_HIP_CHECK(hipMemcpyAsync(land, imgs + (size_t)f0 * img_stride, row_stride * (size_t)hh * (n - 1) + frameBytes,
+                                              hipMemcpyHostToDevice, h->stream));
+            } else {
+                for (int f = 0; f < n; f++)
+                    ORBX_HIP_CHECK(hipMemcpyAsync(land + (size_t)f * row_stride * hh, imgs + (size_t)(f0 + f) * img_stride,
+                                                  frameBytes, hipMemcpyHostToDevice, h->stream));
+            }
+            if (!direct)
+                ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage, sp, h->dRawStage, row_stride, (size_t)w, (size_t)hh * n,
+                                                hipMemcpyDeviceToDevice, h->stream));
             img0.base = h->dImgStage;
             img0.pitch = (int)sp;
             img0.frameStride = (i64)sp * hh;
