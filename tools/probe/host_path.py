@@ -40,3 +40,18 @@ kps2, desc2, n2 = ex.extract_batch(big[:, :, 20:1261])
 dt = time.perf_counter() - t0
 print("1241x376, strided view: %.0f frames/s; same results: %s" % (len(imgs) / dt, bool(np.array_equal(n, n2) and np.array_equal(desc, desc2))))
 ex.close()
+
+# single-frame latency of the drop-in call (host image in, host keypoints out)
+ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=1)
+img = synth.synth_image(640, 480, 3)
+for _ in range(5):
+    ex(img, None)
+lat = []
+for _ in range(200):
+    t0 = time.perf_counter()
+    k, d = ex(img, None)
+    lat.append(time.perf_counter() - t0)
+lat = np.array(lat) * 1e6
+print("one 640x480 frame per call: median %.0f us, p90 %.0f us, min %.0f us (%d keypoints)" % (
+    np.median(lat), np.percentile(lat, 90), lat.min(), len(k)))
+ex.close()
