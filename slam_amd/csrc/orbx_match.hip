@@ -565,6 +565,143 @@ __global__ __launch_bounds__(64) void k_projq_resolve(DevFrame train, ProjQuerie
                                                         int* qBest, int* qBin, int* nmatchesOut) {
     projq_resolve_body(train, q, pol, offs, candIdx, candDist, claimed, claimedObs, qBest, qBin, nmatchesOut);
 }
+// Wave-wide minimum of a 32-bit key, in every lane's return value: DPP row shifts, then the two row broadcasts.
+__device__ __forceinline__ u32 wave_min_u32_dpp(u32 v) {
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// The same sequential resolution with the whole problem in LDS: candidates as (distance << 16 | train
+// index), the per-query offsets, one "held" byte and (for the ratio test) the pyramid level per train
+// keypoint, one "has observations" byte per query.  The workgroup copies them in, wave 0 walks the
+// queries in index order without reading global memory (a query costs a few LDS round trips and a DPP
+// reduction instead of three dependent global loads), then all threads bin the rotations and apply the
+// histogram cull.  Used when the problem fits (the host checks the byte count).
+__global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQueries q, ProjPolicy pol,
+                                                            const int* __restrict__ offs, const int* __restrict__ candIdx,
+                                                            const int* __restrict__ candDist, int* claimed, u8* claimedObs,
+                                                            int* qBest, int* qBin, int* nmatchesOut, int total) {
+    extern __shared__ __align__(16) u8 rsm[];
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int counters[2];  // matches, removed
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = q.n, nt = train.n;
+    u32* cand = (u32*)rsm;
+    int* off = (int*)(cand + total);          // off[i] is overwritten with query i's result once it is known
+    int* level = off + n + 1;                  // nt entries with the ratio test, none without
+    u8* held = (u8*)(level + (pol.ratioTest ? nt : 0));
+    u8* obs = held + nt;
+    for (int k = tid; k < total; k += 256) cand[k] = ((u32)candDist[k] << 16) | (u32)candIdx[k];
+    for (int i = tid; i <= n; i += 256) off[i] = offs[i];
+    for (int i = tid; i < nt; i += 256) {
+        held[i] = (claimed[i] >= 0 && (pol.claimRule == 1 || claimedObs[i])) ? 1 : 0;
+        if (pol.ratioTest) level[i] = train.kps[i].octave;
+    }
+    for (int i = tid; i < n; i += 256) obs[i] = q.hasObs ? q.hasObs[i] : 1;
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid < 2) counters[tid] = 0;
+    __syncthreads();
+    if (tid < 64) {
+        int nmatches = 0;
+        int b = off[0];
+        for (int i = 0; i < n; i++) {
+            const int e = off[i + 1];
+            int best = -1;
+            if (e > b) {
+                u32 key = 0xFFFFFFFFu;
+                for (int k = b + lane; k < e; k += 64) {
+                    const u32 c = cand[k];
+                    if (held[c & 0xFFFFu]) continue;
+                    key = min(key, (c & 0xFFFF0000u) | (u32)(k - b));
+                }
+                key = wave_min_u32_dpp(key);
+                const int bestDist = (int)(key >> 16);
+                if (key != 0xFFFFFFFFu && bestDist < 256 && bestDist <= pol.maxDist) {
+                    const int bestPos = (int)(key & 0xFFFFu);
+                    best = (int)(cand[b + bestPos] & 0xFFFFu);
+                    if (pol.ratioTest) {
+                        u32 kp = 0xFFFFFFFFu, kq = 0xFFFFFFFFu;  // first minimum before / after the best
+                        for (int k = b + lane; k < e; k += 64) {
+                            const int pos = k - b;
+                            if (pos == bestPos) continue;
+                            const u32 c = cand[k];
+                            if (held[c & 0xFFFFu]) continue;
+                            const u32 kk = (c & 0xFFFF0000u) | (u32)pos;
+                            if (pos < bestPos) kp = min(kp, kk);
+                            else kq = min(kq, kk);
+                        }
+                        kp = wave_min_u32_dpp(kp);
+                        kq = wave_min_u32_dpp(kq);
+                        int second = 256, level2 = -1;
+                        if (kp != 0xFFFFFFFFu && (int)(kp >> 16) < 256) {
+                            second = (int)(kp >> 16);
+                            level2 = level[cand[b + (int)(kp & 0xFFFFu)] & 0xFFFFu];
+                        }
+                        if (kq != 0xFFFFFFFFu && (int)(kq >> 16) < second) {
+                            second = (int)(kq >> 16);
+                            level2 = level[cand[b + (int)(kq & 0xFFFFu)] & 0xFFFFu];
+                        }
+                        if (level[best] == level2 && (float)bestDist > __fmul_rn(pol.nnRatio, (float)second)) best = -1;
+                    }
+                }
+            }
+            if (best >= 0) {
+                nmatches++;
+                if (lane == 0) {
+                    const u8 o = obs[i];
+                    held[best] = (pol.claimRule == 1 || o) ? 1 : 0;
+                    claimed[best] = i;
+                    claimedObs[best] = o;
+                }
+            }
+            if (lane == 0) off[i] = best;
+            b = e;
+        }
+        if (lane == 0) counters[0] = nmatches;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int best = off[i];
+        int bin = -1;
+        if (best >= 0 && pol.checkOri) {
+            bin = rot_bin(q.angle[i], train.kps[best].angle);
+            atomicAdd(&hist[bin], 1);
+        }
+        qBest[i] = best;
+        qBin[i] = bin;
+    }
+    __syncthreads();
+    if (pol.checkOri) {
+        if (tid == 0) {
+            int i1 = -1, i2 = -1, i3 = -1;
+            three_maxima(hist, HISTO_LENGTH, i1, i2, i3);
+            keep[0] = i1;
+            keep[1] = i2;
+            keep[2] = i3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int i = tid; i < n; i += 256) {
+            const int best = off[i];
+            if (best < 0) continue;
+            const int bin = rot_bin(q.angle[i], train.kps[best].angle);
+            if (bin != keep[0] && bin != keep[1] && bin != keep[2]) {
+                claimed[best] = -1;
+                claimedObs[best] = 0;
+                removed++;
+            }
+        }
+        if (removed) atomicAdd(&counters[1], removed);
+        __syncthreads();
+    }
+    if (tid == 0) *nmatchesOut = counters[0] - counters[1];
+}
 __global__ __launch_bounds__(64) void k_projq_resolve_jobs(const ProjJob* __restrict__ jobs, ProjPolicy pol) {
     const ProjJob& J = jobs[blockIdx.x];
     projq_resolve_body(J.train, J.q, pol, J.offs, J.candIdx, J.candDist, J.claimed, J.claimedObs, J.qBest, J.qBin, J.nmatches);
@@ -1452,6 +1589,7 @@ struct orbm_context {
     std::vector<std::pair<void*, size_t>> pool;
     std::vector<unsigned char> jobsHost;  // host image of the job table of a batched call
     std::vector<int> totalsHost;
+    bool resolveLdsReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
 };
 
 namespace {
@@ -1803,8 +1941,20 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
         if ((rc = pool_get(m, SL_STATE_C, (size_t)nq * 4, &p3))) return rc;
         dQBest = (int*)p3;
     }
-    hipLaunchKernelGGL(k_projq_resolve, dim3(1), dim3(64), 0, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
-                       (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal);
+    // the whole problem in LDS when it fits (any ordinary frame pair does): see k_projq_resolve_lds
+    const size_t ldsBytes = (size_t)total * 4 + ((size_t)nq + 1) * 4 + (pol.ratioTest ? (size_t)nt * 4 : 0) + (size_t)nt + (size_t)nq + 16;
+    if (ldsBytes <= 150 * 1024 && total < 65536 && nt <= 65536) {
+        if (!m->resolveLdsReady) {
+            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               150 * 1024));
+            m->resolveLdsReady = true;
+        }
+        hipLaunchKernelGGL(k_projq_resolve_lds, dim3(1), dim3(256), ldsBytes, m->stream, train, q, pol, (const int*)offs,
+                           (const int*)cIdx, (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal, total);
+    } else {
+        hipLaunchKernelGGL(k_projq_resolve, dim3(1), dim3(64), 0, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
+                           (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal);
+    }
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)claimed, (const int*)dClaim, (size_t)nt, mem_space))) return rc;
     if ((rc = copy_back(m, claimed_obs, (const u8*)dClaimObs, (size_t)nt, mem_space))) return rc;
