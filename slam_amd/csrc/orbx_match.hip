@@ -98,13 +98,26 @@ __device__ __forceinline__ void grid_build_body(DevFrame f, int* cellStart, int*
         cellStart[GRID_CELLS] = run;
     }
     __syncthreads();
-    // rank inside the cell = number of earlier keypoints in the same cell
-    for (int i = tid; i < f.n; i += 1024) {
-        const u16 c = cellOf[i];
-        if (c == 0xFFFF) continue;
-        int r = 0;
-        for (int j = 0; j < i; j++) r += (cellOf[j] == c);
-        cellItems[hist[c] + r] = i;
+    // Items of a cell keep ascending keypoint order: one wave walks the keypoints 64 at a time, ranks a
+    // keypoint among the lower lanes that fall in the same cell and advances the cell's write cursor
+    // (hist[] holds it) by the number the chunk put there.  Linear in the number of keypoints.
+    if (tid < 64) {
+        for (int base = 0; base < f.n; base += 64) {
+            const int i = base + lane;
+            const int c = i < f.n ? (int)cellOf[i] : 0xFFFF;
+            int r = 0, cnt = 0;
+            for (int l = 0; l < 64; l++) {
+                const int cl = __builtin_amdgcn_readlane(c, l);
+                const bool same = cl == c;
+                r += (same && l < lane) ? 1 : 0;
+                cnt += same ? 1 : 0;
+            }
+            if (c != 0xFFFF) {
+                const int start = hist[c];
+                cellItems[start + r] = i;
+                if (r == cnt - 1) hist[c] = start + cnt;  // the last of the cell in this chunk moves the cursor
+            }
+        }
     }
 }
 
@@ -576,12 +589,20 @@ __device__ __forceinline__ u32 wave_min_u32_dpp(u32 v) {
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// The same sequential resolution with the whole problem in LDS: candidates as (distance << 16 | train
-// index), the per-query offsets, one "held" byte and (for the ratio test) the pyramid level per train
-// keypoint, one "has observations" byte per query.  The workgroup copies them in, wave 0 walks the
-// queries in index order without reading global memory (a query costs a few LDS round trips and a DPP
-// reduction instead of three dependent global loads), then all threads bin the rotations and apply the
-// histogram cull.  Used when the problem fits (the host checks the byte count).
+// The same resolution with the whole problem in LDS (candidates as distance << 16 | train index, the
+// per-query offsets, the claim state per train keypoint, the pyramid levels for the ratio test), used
+// when it fits (the host checks the byte count).  Queries are taken 64 at a time, one per lane:
+//   1. every pending lane scans its candidates exactly as the reference's loop does, against the state
+//      left by everything committed so far;
+//   2. lanes publish the keypoint they would claim (LDS atomic min of the lane number), and a lane
+//      whose candidate list contains a keypoint published by an EARLIER pending lane is "dirty";
+//   3. all pending lanes below the lowest dirty one commit: none of their candidates is touched by an
+//      earlier uncommitted query, so what they computed is what the sequential order gives, and no two
+//      of them claim the same keypoint; the rest repeat from 1 against the new state.
+// The lowest pending lane is never dirty, so every round commits at least one query; with the handful
+// of candidates a projected query has, conflicts inside 64 queries are rare and a chunk takes a few
+// rounds.  Claims live in LDS and are written back once at the end.
+template <bool RATIO>
 __global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQueries q, ProjPolicy pol,
                                                             const int* __restrict__ offs, const int* __restrict__ candIdx,
                                                             const int* __restrict__ candDist, int* claimed, u8* claimedObs,
@@ -594,14 +615,22 @@ __global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQ
     const int n = q.n, nt = train.n;
     u32* cand = (u32*)rsm;
     int* off = (int*)(cand + total);          // off[i] is overwritten with query i's result once it is known
-    int* level = off + n + 1;                  // nt entries with the ratio test, none without
-    u8* held = (u8*)(level + (pol.ratioTest ? nt : 0));
-    u8* obs = held + nt;
+    u32* first = (u32*)(off + n + 1);          // lowest pending lane that wants this keypoint in the current round
+    int* owner = (int*)(first + nt);           // claimed[]
+    int* level = owner + nt;                   // nt entries with the ratio test, none without
+    u8* held = (u8*)(level + (RATIO ? nt : 0));
+    u8* ownerObs = held + nt;                  // claimedObs[]
+    u8* obs = ownerObs + nt;
     for (int k = tid; k < total; k += 256) cand[k] = ((u32)candDist[k] << 16) | (u32)candIdx[k];
     for (int i = tid; i <= n; i += 256) off[i] = offs[i];
     for (int i = tid; i < nt; i += 256) {
-        held[i] = (claimed[i] >= 0 && (pol.claimRule == 1 || claimedObs[i])) ? 1 : 0;
-        if (pol.ratioTest) level[i] = train.kps[i].octave;
+        const int c = claimed[i];
+        const u8 o = claimedObs[i];
+        owner[i] = c;
+        ownerObs[i] = o;
+        held[i] = (c >= 0 && (pol.claimRule == 1 || o)) ? 1 : 0;
+        first[i] = 0xFFFFFFFFu;
+        if (RATIO) level[i] = train.kps[i].octave;
     }
     for (int i = tid; i < n; i += 256) obs[i] = q.hasObs ? q.hasObs[i] : 1;
     if (tid < HISTO_LENGTH) hist[tid] = 0;
@@ -609,59 +638,105 @@ __global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQ
     __syncthreads();
     if (tid < 64) {
         int nmatches = 0;
-        int b = off[0];
-        for (int i = 0; i < n; i++) {
-            const int e = off[i + 1];
-            int best = -1;
-            if (e > b) {
-                u32 key = 0xFFFFFFFFu;
-                for (int k = b + lane; k < e; k += 64) {
-                    const u32 c = cand[k];
-                    if (held[c & 0xFFFFu]) continue;
-                    key = min(key, (c & 0xFFFF0000u) | (u32)(k - b));
-                }
-                key = wave_min_u32_dpp(key);
-                const int bestDist = (int)(key >> 16);
-                if (key != 0xFFFFFFFFu && bestDist < 256 && bestDist <= pol.maxDist) {
-                    const int bestPos = (int)(key & 0xFFFFu);
-                    best = (int)(cand[b + bestPos] & 0xFFFFu);
-                    if (pol.ratioTest) {
-                        u32 kp = 0xFFFFFFFFu, kq = 0xFFFFFFFFu;  // first minimum before / after the best
-                        for (int k = b + lane; k < e; k += 64) {
-                            const int pos = k - b;
-                            if (pos == bestPos) continue;
+        for (int q0 = 0; q0 < n; q0 += 64) {
+            const int i = q0 + lane;
+            const bool have = i < n;
+            const int b = have ? off[i] : 0, e = have ? off[i + 1] : 0;
+            // the first RCACHE candidates of the lane stay in registers for all rounds of the chunk, so a
+            // round is a few batches of independent LDS reads rather than a chain of dependent ones
+            constexpr int RCACHE = 8;
+            u32 cw[RCACHE];
+#pragma unroll
+            for (int j = 0; j < RCACHE; j++) cw[j] = b + j < e ? cand[b + j] : 0xFFFFFFFFu;
+            u64 pending = __ballot(have);
+            while (pending) {
+                const bool mine = (pending >> lane) & 1ull;
+                int result = -1;
+                {
+                    // Keys (distance << 16 | position) of the candidates that are not held; the reference's
+                    // strict '<' scan from 256 keeps the first minimum, i.e. the smallest key.  Its second
+                    // best (src/ORBmatcher.cc:121-134) is what the scan leaves: the first minimum before
+                    // the best, replaced by the first minimum after it only if strictly smaller.
+                    u32 key[RCACHE];
+#pragma unroll
+                    for (int j = 0; j < RCACHE; j++) {
+                        const u32 c = cw[j];  // 0xFFFFFFFF past the end of the list: distance field >= 256
+                        const bool ok = mine && b + j < e && held[c & 0xFFFFu] == 0;
+                        key[j] = ok ? ((c & 0xFFFF0000u) | (u32)j) : 0xFFFFFFFFu;
+                    }
+                    u32 bestKey = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int j = 0; j < RCACHE; j++) bestKey = min(bestKey, key[j]);
+                    if (mine) {
+                        for (int k = b + RCACHE; k < e; k++) {
                             const u32 c = cand[k];
-                            if (held[c & 0xFFFFu]) continue;
-                            const u32 kk = (c & 0xFFFF0000u) | (u32)pos;
-                            if (pos < bestPos) kp = min(kp, kk);
-                            else kq = min(kq, kk);
+                            if (held[c & 0xFFFFu] == 0) bestKey = min(bestKey, (c & 0xFFFF0000u) | (u32)(k - b));
                         }
-                        kp = wave_min_u32_dpp(kp);
-                        kq = wave_min_u32_dpp(kq);
-                        int second = 256, level2 = -1;
-                        if (kp != 0xFFFFFFFFu && (int)(kp >> 16) < 256) {
-                            second = (int)(kp >> 16);
-                            level2 = level[cand[b + (int)(kp & 0xFFFFu)] & 0xFFFFu];
+                    }
+                    const int bestDist = (int)(bestKey >> 16);
+                    if (bestKey != 0xFFFFFFFFu && bestDist < 256 && bestDist <= pol.maxDist) {
+                        const int bestPos = (int)(bestKey & 0xFFFFu);
+                        u32 bw = cw[0];
+#pragma unroll
+                        for (int j = 1; j < RCACHE; j++) bw = bestPos == j ? cw[j] : bw;
+                        if (bestPos >= RCACHE) bw = cand[b + bestPos];
+                        result = (int)(bw & 0xFFFFu);
+                        if (RATIO) {
+                            u32 kp = 0xFFFFFFFFu, kq = 0xFFFFFFFFu;
+#pragma unroll
+                            for (int j = 0; j < RCACHE; j++) {
+                                kp = j < bestPos ? min(kp, key[j]) : kp;
+                                kq = j > bestPos ? min(kq, key[j]) : kq;
+                            }
+                            for (int k = b + RCACHE; k < e; k++) {
+                                const int pos = k - b;
+                                if (pos == bestPos) continue;
+                                const u32 c = cand[k];
+                                if (held[c & 0xFFFFu]) continue;
+                                const u32 kk = (c & 0xFFFF0000u) | (u32)pos;
+                                if (pos < bestPos) kp = min(kp, kk);
+                                else kq = min(kq, kk);
+                            }
+                            int second = 256, level2 = -1;
+                            if (kp != 0xFFFFFFFFu && (int)(kp >> 16) < 256) {
+                                second = (int)(kp >> 16);
+                                level2 = level[cand[b + (int)(kp & 0xFFFFu)] & 0xFFFFu];
+                            }
+                            if (kq != 0xFFFFFFFFu && (int)(kq >> 16) < second) {
+                                second = (int)(kq >> 16);
+                                level2 = level[cand[b + (int)(kq & 0xFFFFu)] & 0xFFFFu];
+                            }
+                            if (level[result] == level2 && (float)bestDist > __fmul_rn(pol.nnRatio, (float)second)) result = -1;
                         }
-                        if (kq != 0xFFFFFFFFu && (int)(kq >> 16) < second) {
-                            second = (int)(kq >> 16);
-                            level2 = level[cand[b + (int)(kq & 0xFFFFu)] & 0xFFFFu];
-                        }
-                        if (level[best] == level2 && (float)bestDist > __fmul_rn(pol.nnRatio, (float)second)) best = -1;
                     }
                 }
-            }
-            if (best >= 0) {
-                nmatches++;
-                if (lane == 0) {
-                    const u8 o = obs[i];
-                    held[best] = (pol.claimRule == 1 || o) ? 1 : 0;
-                    claimed[best] = i;
-                    claimedObs[best] = o;
+                const bool wants = mine && result >= 0;
+                if (wants) atomicMin(&first[result], (u32)lane);
+                bool dirty = false;
+                if (mine) {
+                    u32 fl[RCACHE];
+#pragma unroll
+                    for (int j = 0; j < RCACHE; j++) fl[j] = b + j < e ? first[cw[j] & 0xFFFFu] : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int j = 0; j < RCACHE; j++) dirty |= fl[j] < (u32)lane;
+                    for (int k = b + RCACHE; k < e; k++) dirty |= first[cand[k] & 0xFFFFu] < (u32)lane;
                 }
+                if (wants) first[result] = 0xFFFFFFFFu;  // leave the table clean for the next round
+                const u64 dm = __ballot(mine && dirty);
+                const int d = dm ? __ffsll((unsigned long long)dm) - 1 : 64;
+                const bool commit = mine && lane < d;
+                if (commit) {
+                    off[i] = result;
+                    if (result >= 0) {
+                        const u8 o = obs[i];
+                        held[result] = (pol.claimRule == 1 || o) ? 1 : 0;
+                        owner[result] = i;
+                        ownerObs[result] = o;
+                    }
+                }
+                nmatches += __popcll(__ballot(commit && result >= 0));
+                pending &= ~__ballot(commit);
             }
-            if (lane == 0) off[i] = best;
-            b = e;
         }
         if (lane == 0) counters[0] = nmatches;
     }
@@ -692,13 +767,17 @@ __global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQ
             if (best < 0) continue;
             const int bin = rot_bin(q.angle[i], train.kps[best].angle);
             if (bin != keep[0] && bin != keep[1] && bin != keep[2]) {
-                claimed[best] = -1;
-                claimedObs[best] = 0;
+                owner[best] = -1;
+                ownerObs[best] = 0;
                 removed++;
             }
         }
         if (removed) atomicAdd(&counters[1], removed);
         __syncthreads();
+    }
+    for (int i = tid; i < nt; i += 256) {
+        claimed[i] = owner[i];
+        claimedObs[i] = ownerObs[i];
     }
     if (tid == 0) *nmatchesOut = counters[0] - counters[1];
 }
@@ -1942,15 +2021,18 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
         dQBest = (int*)p3;
     }
     // the whole problem in LDS when it fits (any ordinary frame pair does): see k_projq_resolve_lds
-    const size_t ldsBytes = (size_t)total * 4 + ((size_t)nq + 1) * 4 + (pol.ratioTest ? (size_t)nt * 4 : 0) + (size_t)nt + (size_t)nq + 16;
+    const size_t ldsBytes = (size_t)total * 4 + ((size_t)nq + 1) * 4 + (size_t)nt * (8 + (pol.ratioTest ? 4 : 0) + 2) + (size_t)nq + 16;
     if (ldsBytes <= 150 * 1024 && total < 65536 && nt <= 65536) {
         if (!m->resolveLdsReady) {
-            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               150 * 1024));
+            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds<false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds<true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             m->resolveLdsReady = true;
         }
-        hipLaunchKernelGGL(k_projq_resolve_lds, dim3(1), dim3(256), ldsBytes, m->stream, train, q, pol, (const int*)offs,
-                           (const int*)cIdx, (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal, total);
+        auto kr = pol.ratioTest ? k_projq_resolve_lds<true> : k_projq_resolve_lds<false>;
+        hipLaunchKernelGGL(kr, dim3(1), dim3(256), ldsBytes, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
+                           (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal, total);
     } else {
         hipLaunchKernelGGL(k_projq_resolve, dim3(1), dim3(64), 0, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
                            (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal);
