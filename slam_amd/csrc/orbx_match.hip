@@ -1669,15 +1669,29 @@ struct orbm_context {
     std::vector<unsigned char> jobsHost;  // host image of the job table of a batched call
     std::vector<int> totalsHost;
     bool resolveLdsReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
+    // Host arrays travel through one pinned arena per call: copies from and to pageable memory are staged
+    // and serialised by the runtime (10-15 us each), copies from pinned memory are plain queue entries.
+    // Results land in the arena and are handed to the caller's arrays after the stream has been waited for.
+    unsigned char* arena = nullptr;
+    size_t arenaCap = 0, arenaUsed = 0;
+    std::vector<void*> arenaRetired;
+    struct Delivery {
+        void* dst;
+        const void* src;
+        size_t bytes;
+    };
+    std::vector<Delivery> pending;
 };
 
 namespace {
+
+hipError_t sync_deliver(orbm_context* m);
 
 int pool_get(orbm_context* m, int slot, size_t bytes, void** out) {
     if ((int)m->pool.size() <= slot) m->pool.resize(slot + 1, std::make_pair((void*)nullptr, (size_t)0));
     std::pair<void*, size_t>& e = m->pool[slot];
     if (e.second < bytes) {
-        ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        ORBX_HIP_CHECK(sync_deliver(m));
         if (e.first) (void)hipFree(e.first);
         e.first = nullptr;
         e.second = 0;
@@ -1701,6 +1715,62 @@ enum {
 };
 
 // Device view of a caller array: the pointer itself for device memory, else a staged copy.
+// ---- pinned staging (host memory mode)
+void* arena_alloc(orbm_context* m, size_t bytes) {
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (m->arenaUsed + need > m->arenaCap) {
+        // blocks handed out earlier in this call stay valid: the old arena is kept until the next call
+        const size_t cap = std::max(m->arenaCap * 2, std::max(need * 2, (size_t)1 << 20));
+        void* p = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+            orbx_set_error("hipHostMalloc of %zu bytes failed", cap);
+            return nullptr;
+        }
+        if (m->arena) m->arenaRetired.push_back(m->arena);
+        m->arena = (unsigned char*)p;
+        m->arenaCap = cap;
+        m->arenaUsed = 0;
+    }
+    void* r = m->arena + m->arenaUsed;
+    m->arenaUsed += need;
+    return r;
+}
+
+// Start of an entry point: nothing of the previous call is in flight any more (host-mode calls end with
+// sync_deliver), so the arena starts over.
+void arena_reset(orbm_context* m) {
+    m->arenaUsed = 0;
+    for (void* p : m->arenaRetired) (void)hipHostFree(p);
+    m->arenaRetired.clear();
+    m->pending.clear();
+}
+
+int h2d(orbm_context* m, void* dev, const void* host, size_t bytes) {
+    if (!bytes) return ORBX_OK;
+    void* p = arena_alloc(m, bytes);
+    if (!p) return ORBX_ERR_HIP;
+    memcpy(p, host, bytes);
+    ORBX_HIP_CHECK(hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, m->stream));
+    return ORBX_OK;
+}
+
+int d2h(orbm_context* m, void* host, const void* dev, size_t bytes) {
+    if (!bytes) return ORBX_OK;
+    void* p = arena_alloc(m, bytes);
+    if (!p) return ORBX_ERR_HIP;
+    ORBX_HIP_CHECK(hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, m->stream));
+    m->pending.push_back({host, p, bytes});
+    return ORBX_OK;
+}
+
+hipError_t sync_deliver(orbm_context* m) {
+    const hipError_t e = hipStreamSynchronize(m->stream);
+    if (e != hipSuccess) return e;
+    for (const auto& d : m->pending) memcpy(d.dst, d.src, d.bytes);
+    m->pending.clear();
+    return hipSuccess;
+}
+
 template <typename T>
 int stage_in(orbm_context* m, int slot, const T* src, size_t count, int memSpace, const T** out) {
     if (memSpace == ORBX_MEM_DEVICE || src == nullptr) {
@@ -1710,7 +1780,7 @@ int stage_in(orbm_context* m, int slot, const T* src, size_t count, int memSpace
     void* d = nullptr;
     int rc = pool_get(m, slot, std::max(count, (size_t)1) * sizeof(T), &d);
     if (rc) return rc;
-    if (count) ORBX_HIP_CHECK(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, m->stream));
+    if ((rc = h2d(m, d, src, count * sizeof(T)))) return rc;
     *out = (const T*)d;
     return ORBX_OK;
 }
@@ -1731,8 +1801,7 @@ int stage_out(orbm_context* m, int slot, T* dst, size_t count, int memSpace, T**
 template <typename T>
 int copy_back(orbm_context* m, T* host, const T* dev, size_t count, int memSpace) {
     if (memSpace == ORBX_MEM_DEVICE || count == 0) return ORBX_OK;
-    ORBX_HIP_CHECK(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, m->stream));
-    return ORBX_OK;
+    return d2h(m, host, dev, count * sizeof(T));
 }
 
 int make_frame(orbm_context* m, const orbm_frame* f, int slotKps, int slotDesc, int memSpace, DevFrame* out) {
@@ -1780,6 +1849,7 @@ int use_device(orbm_context* m) {
         return ORBX_ERR_INVALID;
     }
     ORBX_HIP_CHECK(hipSetDevice(m->device));
+    arena_reset(m);
     return ORBX_OK;
 }
 
@@ -1828,20 +1898,22 @@ void orbm_destroy(orbm_context* m) {
     (void)hipStreamSynchronize(m->stream);
     for (auto& e : m->pool)
         if (e.first) (void)hipFree(e.first);
+    for (void* p : m->arenaRetired) (void)hipHostFree(p);
+    if (m->arena) (void)hipHostFree(m->arena);
     if (m->ownStream) (void)hipStreamDestroy(m->ownStream);
     delete m;
 }
 
 int orbm_set_stream(orbm_context* m, void* hip_stream) {
     if (!m) return ORBX_ERR_INVALID;
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ORBX_HIP_CHECK(sync_deliver(m));
     m->stream = hip_stream ? (hipStream_t)hip_stream : m->ownStream;
     return ORBX_OK;
 }
 
 int orbm_synchronize(orbm_context* m) {
     if (!m) return ORBX_ERR_INVALID;
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -1860,7 +1932,7 @@ int orbm_grid_build(orbm_context* m, const orbm_frame* f, int32_t* cell_start, i
         if (df.n) ORBX_HIP_CHECK(hipMemcpyAsync(cell_items, ci, (size_t)df.n * sizeof(int), hipMemcpyDeviceToDevice, m->stream));
     } else {
         ORBX_HIP_CHECK(hipMemcpyAsync(cell_start, cs, (GRID_CELLS + 1) * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-        ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+        ORBX_HIP_CHECK(sync_deliver(m));
         const int total = cell_start[GRID_CELLS];
         if (total) ORBX_HIP_CHECK(hipMemcpy(cell_items, ci, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
     }
@@ -1901,7 +1973,7 @@ int orbm_window_candidates(orbm_context* m, const orbm_frame* train, const float
     if ((rc = copy_back(m, (int*)cand_idx, dIdx, rows, mem_space))) return rc;
     if (cand_dist && (rc = copy_back(m, (int*)cand_dist, dDist, rows, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)counts, dCnt, (size_t)nq, mem_space))) return rc;
-    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -1930,7 +2002,7 @@ int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const 
         void* p;
         if ((rc = pool_get(m, SL_PREV, (size_t)n1 * 2 * sizeof(float), &p))) return rc;
         dPrev = (float*)p;
-        ORBX_HIP_CHECK(hipMemcpyAsync(dPrev, prev_matched_xy, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice, m->stream));
+        if ((rc = h2d(m, dPrev, prev_matched_xy, (size_t)n1 * 2 * sizeof(float)))) return rc;
     }
     if ((rc = pool_get(m, SL_QX, (size_t)n1 * 4, &qx)) || (rc = pool_get(m, SL_QY, (size_t)n1 * 4, &qy)) ||
         (rc = pool_get(m, SL_QR, (size_t)n1 * 4, &qr)) || (rc = pool_get(m, SL_QMIN, (size_t)n1 * 4, &qmin)) ||
@@ -1946,8 +2018,8 @@ int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const 
                        0, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, n1);
     int total = 0;
-    ORBX_HIP_CHECK(hipMemcpyAsync(&total, (int*)offs + n1, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = d2h(m, &total, (int*)offs + n1, sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
     void *cIdx, *cDist;
     if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
         (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
@@ -1962,8 +2034,8 @@ int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const 
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)matches12, (const int*)dM12, (size_t)n1, mem_space))) return rc;
     if ((rc = copy_back(m, prev_matched_xy, (const float*)dPrev, (size_t)n1 * 2, mem_space))) return rc;
-    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, scal, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = d2h(m, nmatches, scal, sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -1991,8 +2063,8 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
                        dTrainURight, q, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, nq);
     int total = 0;
-    ORBX_HIP_CHECK(hipMemcpyAsync(&total, (int*)offs + nq, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = d2h(m, &total, (int*)offs + nq, sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
     void *cIdx, *cDist;
     if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
         (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
@@ -2010,8 +2082,7 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
         if ((rc = pool_get(m, SL_STATE_A, (size_t)nt * 4, &p1)) || (rc = pool_get(m, SL_STATE_B, (size_t)nt, &p2))) return rc;
         dClaim = (int*)p1;
         dClaimObs = (u8*)p2;
-        ORBX_HIP_CHECK(hipMemcpyAsync(dClaim, claimed, (size_t)nt * 4, hipMemcpyHostToDevice, m->stream));
-        ORBX_HIP_CHECK(hipMemcpyAsync(dClaimObs, claimed_obs, (size_t)nt, hipMemcpyHostToDevice, m->stream));
+        if ((rc = h2d(m, dClaim, claimed, (size_t)nt * 4)) || (rc = h2d(m, dClaimObs, claimed_obs, (size_t)nt))) return rc;
     }
     if (mem_space == ORBX_MEM_DEVICE && query_best) {
         dQBest = (int*)query_best;
@@ -2041,8 +2112,8 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
     if ((rc = copy_back(m, (int*)claimed, (const int*)dClaim, (size_t)nt, mem_space))) return rc;
     if ((rc = copy_back(m, claimed_obs, (const u8*)dClaimObs, (size_t)nt, mem_space))) return rc;
     if (query_best && (rc = copy_back(m, (int*)query_best, (const int*)dQBest, (size_t)nq, mem_space))) return rc;
-    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, scal, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = d2h(m, nmatches, scal, sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2234,7 +2305,7 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     ORBX_HIP_CHECK(hipGetLastError());
     m->totalsHost.resize((size_t)npairs);
     ORBX_HIP_CHECK(hipMemcpyAsync(m->totalsHost.data(), dTot, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ORBX_HIP_CHECK(sync_deliver(m));
     size_t total = 0;
     for (int i = 0; i < npairs; i++) total += (size_t)m->totalsHost[i];
     void *cIdx, *cDist;
@@ -2253,7 +2324,7 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     hipLaunchKernelGGL(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
     ORBX_HIP_CHECK(hipGetLastError());
     ORBX_HIP_CHECK(hipMemcpyAsync(m->totalsHost.data(), nmArr, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ORBX_HIP_CHECK(sync_deliver(m));
     for (int i = 0; i < npairs; i++) pairs[i].nmatches = m->totalsHost[i];
     return ORBX_OK;
 }
@@ -2330,8 +2401,8 @@ int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const o
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, u_right, (const float*)dU, (size_t)dl.n, mem_space))) return rc;
     if ((rc = copy_back(m, depth, (const float*)dD, (size_t)dl.n, mem_space))) return rc;
-    if (n_stereo) ORBX_HIP_CHECK(hipMemcpyAsync(n_stereo, dKept, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    if (mem_space == ORBX_MEM_HOST || n_stereo) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (n_stereo && (rc = d2h(m, n_stereo, dKept, sizeof(int)))) return rc;
+    if (mem_space == ORBX_MEM_HOST || n_stereo) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2413,8 +2484,8 @@ int orbm_search_by_bow(orbm_context* m, const orbm_frame* f1, const orbm_feature
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)match21, (const int*)dM21, (size_t)d2.n, mem_space))) return rc;
-    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, dCount, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = d2h(m, nmatches, dCount, sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2475,8 +2546,8 @@ int orbm_search_for_triangulation(orbm_context* m, const orbm_frame* f1, const o
                        (const int*)dBin, (const int*)dHist, dCount);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
-    ORBX_HIP_CHECK(hipMemcpyAsync(nmatches, dCount, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = d2h(m, nmatches, dCount, sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2532,7 +2603,7 @@ int orbm_window_best(orbm_context* m, const orbm_frame* kf, int n, const uint8_t
         return rc;
     if ((rc = copy_back(m, (int*)best_idx, (const int*)dIdx, (size_t)n, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)best_dist, (const int*)dDist, (size_t)n, mem_space))) return rc;
-    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2595,8 +2666,8 @@ int orbm_search_by_sim3(orbm_context* m, const orbm_frame* kf1, const orbm_frame
                        (const int*)i21, (const int*)dd21, dM12, (int*)dCount);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
-    ORBX_HIP_CHECK(hipMemcpyAsync(nfound, dCount, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if ((rc = d2h(m, nfound, dCount, sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2643,7 +2714,7 @@ int orbm_distinctive_descriptors(orbm_context* m, const uint8_t* desc, const int
     if ((rc = copy_back(m, (int*)best, (const int*)dBest, (size_t)ngroups, mem_space))) return rc;
     if (best_median && (rc = copy_back(m, (int*)best_median, (const int*)dMed, (size_t)ngroups, mem_space))) return rc;
     if (out_desc && (rc = copy_back(m, out_desc, (const u8*)dOut, (size_t)ngroups * 32, mem_space))) return rc;
-    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2673,7 +2744,7 @@ int orbm_filter_by_mask(orbm_context* m, const orbx_keypoint* kps, const uint8_t
                        (const u64*)dScal, dOutK, dOutD, (int*)dScal + 4);
     ORBX_HIP_CHECK(hipGetLastError());
     ORBX_HIP_CHECK(hipMemcpyAsync(n_out, (int*)dScal + 4, sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ORBX_HIP_CHECK(sync_deliver(m));
     if (mem_space == ORBX_MEM_HOST && *n_out > 0) {
         ORBX_HIP_CHECK(hipMemcpy(out_kps, dOutK, (size_t)*n_out * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
         ORBX_HIP_CHECK(hipMemcpy(out_desc, dOutD, (size_t)*n_out * 32, hipMemcpyDeviceToHost));
@@ -2702,7 +2773,7 @@ int orbm_pack_keyframe_records(orbm_context* m, const orbx_keypoint* kps, const 
                        (u8*)dDesc, (u64*)dIdx, dRec);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, records, (const u8*)dRec, (size_t)n * 64, mem_space))) return rc;
-    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2729,7 +2800,7 @@ int orbm_unpack_keyframe_records(orbm_context* m, const uint8_t* records, int n,
     if ((rc = copy_back(m, kps, (const orbx_keypoint*)dKps, (size_t)n, mem_space))) return rc;
     if ((rc = copy_back(m, desc, (const u8*)dDesc, (size_t)n * 32, mem_space))) return rc;
     if (mp_index && (rc = copy_back(m, mp_index, (const uint64_t*)dIdx, (size_t)n, mem_space))) return rc;
-    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2768,7 +2839,7 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
     if ((rc = copy_back(m, (int*)best_idx, (const int*)di, (size_t)nq, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)best_d, (const int*)dd, (size_t)nq, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)second_d, (const int*)ds, (size_t)nq, mem_space))) return rc;
-    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
@@ -2799,7 +2870,7 @@ int orbm_knn2_merge(orbm_context* m, int nq, int32_t* best_idx_a, int32_t* best_
     if ((rc = copy_back(m, (int*)best_idx_a, (const int*)ia, (size_t)nq, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)best_d_a, (const int*)da, (size_t)nq, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)second_d_a, (const int*)sa, (size_t)nq, mem_space))) return rc;
-    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 
