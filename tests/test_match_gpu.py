@@ -428,3 +428,19 @@ def test_random_frames_and_parameters_equal_oracle():
         err = fz.run_case(rng, c)
         assert err is None, "case seed %d: %s" % (77000 + case, err)
     assert fz.STATS["proj n"] > 10000 and fz.STATS["bow n"] > 5000
+
+
+def test_large_frames_take_the_global_memory_resolution():
+    """Frames whose candidate lists do not fit LDS (more than 65535 candidates in total) go through
+    the one-wave resolution over global memory: same results as the oracle."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_match.py")
+    spec = importlib.util.spec_from_file_location("fuzz_match_big", path)
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for case in range(3):
+        rng = np.random.default_rng(99100 + case)
+        c = fz.draw_case(rng, npts=9000)
+        err = fz.run_case(rng, c)
+        assert err is None, "case seed %d: %s" % (99100 + case, err)

@@ -38,12 +38,12 @@ def flip_bits(desc, rng, max_flips):
     return d
 
 
-def draw_case(rng):
+def draw_case(rng, npts=None):
     w = float(rng.integers(200, 1300))
     h = float(rng.integers(150, 800))
     off = rng.uniform(-9, 9, 4) if rng.uniform() < 0.5 else np.zeros(4)
     bounds = (float(np.float32(off[0])), float(np.float32(off[1])), float(np.float32(w + off[2])), float(np.float32(h + off[3])))
-    npts = int(rng.choice([0, 1, 3, 40, 300, 1000, 2200]))
+    npts = int(rng.choice([0, 1, 3, 40, 300, 1000, 2200])) if npts is None else npts
     nproto = int(rng.choice([1, 4, 32, 100000]))
     max_flips = int(rng.choice([0, 2, 12, 40]))
     shift = (float(rng.integers(-20, 21)), float(rng.integers(-12, 13)))
