@@ -163,6 +163,18 @@ def main():
                 traffic = tj[dominant]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+    # vector instructions of the dominant kernel per launch, from the committed SQ counter pass (same
+    # 512-frame launches); the kernels on this path are bound by vector-instruction issue, not by HBM
+    valu = None
+    spath = os.path.join(ROOT, "profiles", "r1_sq_counters.csv")
+    if os.path.exists(spath) and frames_per_launch == 512:
+        try:
+            import csv
+            for r in csv.DictReader(open(spath)):
+                if r["kernel"] == KERNEL_OF[dominant]:
+                    valu = float(r["SQ_INSTS_VALU"])
+        except Exception:
+            valu = None
     alg = ALG_BYTES[dominant]
     ach = stages[dominant].get("achieved_GBs", 0.0)
     roofline = {"kernel": KERNEL_OF[dominant], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -172,6 +184,13 @@ def main():
                 "avg_launch_ms_serialized": st2[dominant]["ms_per_launch"],
                 "achieved_serialized": st2[dominant].get("achieved_GBs"),
                 "time_share": round(st2[dominant]["ms_total"] / sum(s["ms_total"] for s in st2.values()), 3)}
+    if valu:
+        per_s = valu / (st2[dominant]["ms_per_launch"] * 1e-3)
+        roofline["valu_issue"] = {"wave_instr_per_launch": int(valu), "wave_instr_per_s_serialized": round(per_s, 1),
+                                  "issue_rate_at_4_cycles": round(1024 * 2.4e9 / 4.0, 1),
+                                  "frac_of_issue_rate": round(per_s / (1024 * 2.4e9 / 4.0), 3),
+                                  "note": "1024 SIMDs at 2.4 GHz; measured 2.3-2.8 cycles per wave64 instruction for "
+                                          "add/sub/and/xor/fma, 4.1-4.5 for the rest (profiles/r1_probes.txt)"}
 
     out = {
         "metric": "ORB frames/s (640x480, 1000kp, 8 lvl)", "value": round(value, 1), "unit": "frames/s",

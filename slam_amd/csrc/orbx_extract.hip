@@ -1358,7 +1358,12 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
                 __builtin_memcpy(&px[j][i], corner + (size_t)mad24(slot >> 3, (u32)im.pitch, (slot & 7) * 4), 4);
             }
         }
-        issue_windows(0);  // the first windows travel while the moments are computed
+        // The first windows travel while the moments are computed.  (Scheduling fences: the first use of
+        // a patch word makes the compiler wait for every load issued so far, so no such use may drift
+        // in between the window loads.)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_windows(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < DESC_KPW; j++) {
             int m10 = 0, m01 = 0;
