@@ -1588,13 +1588,11 @@ __global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int n
         }
     };
     int j = 0;
-    // Four train rows per trip: their scalar loads are issued together, ahead of the math.  The
-    // top-2 update is skipped for a trip unless some lane of the wave met a distance that can
-    // enter its top 2 (distance <= current second-best distance), which soon becomes rare.
-    for (; j + 4 <= nt; j += 4) {
-        uint4 b[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) b[r] = t[(i64)j * 2 + r];
+    // Four train rows per step.  The top-2 update is skipped for a step unless some lane of the wave met
+    // a distance that can enter its top 2 (distance <= current second-best distance), which soon
+    // becomes rare.  Two sets of scalar registers alternate: the rows of the next step are requested
+    // before the current step's math, so a wave does not sit out the scalar-load latency every step.
+    auto step = [&](const uint4* b, int j0) {
         u32 d[KNN_QPT][4];
         bool any = false;
 #pragma unroll
@@ -1609,11 +1607,40 @@ __global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int n
             for (int k = 0; k < KNN_QPT; k++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const u32 key = (d[k][r] << KNN_IDX_BITS) | (u32)(j + r);
+                    const u32 key = (d[k][r] << KNN_IDX_BITS) | (u32)(j0 + r);
                     second[k] = umed3(best[k], second[k], key);
                     best[k] = min(best[k], key);
                 }
             }
+        }
+    };
+    auto load4 = [&](uint4* b, int j0) {
+        // rows past the end are never used; the index is clamped so that the request stays in range
+        const int jc = max(min(j0, nt - 4), 0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) b[r] = t[(i64)jc * 2 + r];
+    };
+    if (nt >= 4) {
+        uint4 ba[8], bb[8];
+        load4(ba, 0);
+        for (; j + 8 <= nt; j += 8) {
+            // Scalar loads return out of order, so they can only be waited for all at once: the set about
+            // to be used is touched (which places that wait) BEFORE the other set is requested, and the
+            // fences keep the request ahead of the math.
+            asm volatile("" ::"s"(ba[0].x));
+            __builtin_amdgcn_sched_barrier(0);
+            load4(bb, j + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            step(ba, j);
+            asm volatile("" ::"s"(bb[0].x));
+            __builtin_amdgcn_sched_barrier(0);
+            load4(ba, j + 8);
+            __builtin_amdgcn_sched_barrier(0);
+            step(bb, j + 4);
+        }
+        if (j + 4 <= nt) {
+            step(ba, j);
+            j += 4;
         }
     }
     for (; j < nt; j++) visit(t[(i64)j * 2], t[(i64)j * 2 + 1], j);
