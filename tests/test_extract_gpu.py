@@ -345,3 +345,36 @@ def test_level_taller_than_twice_its_width_is_rejected(oracle):
             ex(img, None)
         finally:
             ex.close()
+
+
+def test_two_extractors_from_two_threads(oracle):
+    """The reference extracts the left and right image on two threads with two ORBextractor
+    objects (src/Frame.cc:122-125): two handles used concurrently, each from its own thread."""
+    import threading
+    from slam_amd.extractor import ORBextractor
+    imgs = [synth.synth_batch(6, 640, 480, 700), synth.synth_batch(6, 640, 480, 900)]
+    p = oracle.params()
+    want = [[oracle.extract(p, im) for im in side] for side in imgs]
+    exs = [ORBextractor(1000, 1.2, 8, 20, 7), ORBextractor(1000, 1.2, 8, 20, 7)]
+    errors = []
+
+    def work(side):
+        try:
+            for rep in range(5):
+                for f in range(len(imgs[side])):
+                    k, d = exs[side](imgs[side][f], None)
+                    rk, rd = want[side][f]
+                    if k.tobytes() != rk.tobytes() or not np.array_equal(d, rd):
+                        errors.append("side %d frame %d rep %d differs" % (side, f, rep))
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append("side %d: %r" % (side, e))
+
+    threads = [threading.Thread(target=work, args=(s,)) for s in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for ex in exs:
+        ex.close()
+    assert not errors, errors
