@@ -1730,6 +1730,8 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         int maxQuota = 0;
         for (int l = 0; l < g.nlevels; l++) maxQuota = std::max(maxQuota, g.lv[l].quota);
         h->qtThreads = maxQuota >= 1400 ? 1024 : maxQuota >= 700 ? 512 : 256;
+        // a handle for a few frames at a time is used for latency: the widest workgroup finishes a level soonest
+        if (h->cfg.max_batch <= 4) h->qtThreads = 1024;
     }
     if (const char* e = getenv("ORBX_QT_THREADS")) h->qtThreads = atoi(e);
     if (h->qtThreads != 256 && h->qtThreads != 512 && h->qtThreads != 1024) h->qtThreads = 256;
@@ -1971,6 +1973,8 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
                 // destination rows per band: 32 where that still gives the launch enough waves, fewer
                 // on the small levels (a band re-reads about two source rows of its neighbour)
                 int bandRows = RESIZE_BH;
+                // small batches cannot fill the GPU with 32-row bands: shorter bands give more, shorter walks
+                while (bandRows > 4 && (i64)n * ((((L.w + 3) / 4) * ((L.h + bandRows - 1) / bandRows) + 255) / 256) < 1024) bandRows >>= 1;
                 {
                     static int forced[ORBX_MAX_LEVELS] = {-1};
                     if (forced[0] == -1) {
