@@ -603,11 +603,10 @@ __device__ __forceinline__ u32 wave_min_u32_dpp(u32 v) {
 // of candidates a projected query has, conflicts inside 64 queries are rare and a chunk takes a few
 // rounds.  Claims live in LDS and are written back once at the end.
 template <bool RATIO>
-__global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQueries q, ProjPolicy pol,
-                                                            const int* __restrict__ offs, const int* __restrict__ candIdx,
-                                                            const int* __restrict__ candDist, int* claimed, u8* claimedObs,
-                                                            int* qBest, int* qBin, int* nmatchesOut, int total) {
-    extern __shared__ __align__(16) u8 rsm[];
+__device__ __forceinline__ void projq_resolve_lds_body(u8* rsm, DevFrame train, ProjQueries q, ProjPolicy pol,
+                                                        const int* __restrict__ offs, const int* __restrict__ candIdx,
+                                                        const int* __restrict__ candDist, int* claimed, u8* claimedObs,
+                                                        int* qBest, int* qBin, int* nmatchesOut, int total) {
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int counters[2];  // matches, removed
@@ -780,6 +779,22 @@ __global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQ
         claimedObs[i] = ownerObs[i];
     }
     if (tid == 0) *nmatchesOut = counters[0] - counters[1];
+}
+template <bool RATIO>
+__global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQueries q, ProjPolicy pol,
+                                                            const int* __restrict__ offs, const int* __restrict__ candIdx,
+                                                            const int* __restrict__ candDist, int* claimed, u8* claimedObs,
+                                                            int* qBest, int* qBin, int* nmatchesOut, int total) {
+    extern __shared__ __align__(16) u8 rsm[];
+    projq_resolve_lds_body<RATIO>(rsm, train, q, pol, offs, candIdx, candDist, claimed, claimedObs, qBest, qBin, nmatchesOut, total);
+}
+// One job (frame pair) per workgroup; the dynamic LDS is sized by the host for the largest job.
+template <bool RATIO>
+__global__ __launch_bounds__(256) void k_projq_resolve_lds_jobs(const ProjJob* __restrict__ jobs, ProjPolicy pol) {
+    extern __shared__ __align__(16) u8 rsm[];
+    const ProjJob& J = jobs[blockIdx.x];
+    projq_resolve_lds_body<RATIO>(rsm, J.train, J.q, pol, J.offs, J.candIdx, J.candDist, J.claimed, J.claimedObs, J.qBest, J.qBin,
+                                  J.nmatches, J.offs[J.q.n]);
 }
 __global__ __launch_bounds__(64) void k_projq_resolve_jobs(const ProjJob* __restrict__ jobs, ProjPolicy pol) {
     const ProjJob& J = jobs[blockIdx.x];
@@ -1695,7 +1710,7 @@ struct orbm_context {
     std::vector<std::pair<void*, size_t>> pool;
     std::vector<unsigned char> jobsHost;  // host image of the job table of a batched call
     std::vector<int> totalsHost;
-    bool resolveLdsReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
+    bool resolveLdsReady = false, resolveJobsLdsReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
     // Host arrays travel through one pinned arena per call: copies from and to pageable memory are staged
     // and serialised by the runtime (10-15 us each), copies from pinned memory are plain queue entries.
     // Results land in the arena and are handed to the caller's arrays after the stream has been waited for.
@@ -2348,7 +2363,24 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
     if (maxNl > 0) hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, 2);
     ProjPolicy pol = {0, TH_HIGH, 0, 0.f, check_orientation};
-    hipLaunchKernelGGL(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
+    // every job resolved from LDS when the largest one fits (see k_projq_resolve_lds)
+    size_t maxLds = 0;
+    bool fits = true;
+    for (int i = 0; i < npairs; i++) {
+        const size_t tot = (size_t)m->totalsHost[i], nq = (size_t)pairs[i].last.n, nt = (size_t)pairs[i].cur.n;
+        maxLds = std::max(maxLds, tot * 4 + (nq + 1) * 4 + nt * 10 + nq + 16);
+        fits = fits && tot < 65536 && nt <= 65536;
+    }
+    if (fits && maxLds <= 150 * 1024) {
+        if (!m->resolveJobsLdsReady) {
+            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds_jobs<false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            m->resolveJobsLdsReady = true;
+        }
+        hipLaunchKernelGGL(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol);
+    } else {
+        hipLaunchKernelGGL(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
+    }
     ORBX_HIP_CHECK(hipGetLastError());
     ORBX_HIP_CHECK(hipMemcpyAsync(m->totalsHost.data(), nmArr, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
     ORBX_HIP_CHECK(sync_deliver(m));
