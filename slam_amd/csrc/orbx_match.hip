@@ -313,7 +313,8 @@ __device__ __forceinline__ void projq_candidates_body(DevFrame train, const int*
                                                            const int* __restrict__ cellItems,
                                                            const float* __restrict__ trainURight, ProjQueries q, int mode,
                                                            const int* __restrict__ offs, int* candIdx, int* candDist,
-                                                           int* counts) {
+                                                           int* counts, u32* slab = nullptr, int slabCap = 0,
+                                                           int* overflow = nullptr) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= q.n) return;
     Query qq;
@@ -325,10 +326,16 @@ __device__ __forceinline__ void projq_candidates_body(DevFrame train, const int*
             if (mode == 2) {
                 candIdx[rowBase + pos] = idx;
                 candDist[rowBase + pos] = desc_distance(qd, train.desc + (i64)idx * 32);
+            } else if (mode == 3 && pos < slabCap) {
+                // one walk: the first slabCap candidates of the query go to its fixed slot, distance included
+                slab[(i64)i * slabCap + pos] = ((u32)desc_distance(qd, train.desc + (i64)idx * 32) << 16) | (u32)idx;
             }
         });
     }
-    if ((threadIdx.x & 63) == 0 && mode == 0) counts[i] = n;
+    if ((threadIdx.x & 63) == 0 && (mode == 0 || mode == 3)) {
+        counts[i] = n;
+        if (mode == 3 && n > slabCap) atomicOr(overflow, 1);
+    }
 }
 
 // Per-query inputs of SearchByProjection(cur, last): reference src/ORBmatcher.cc:1564-1598,
@@ -528,6 +535,9 @@ struct ProjJob {
     int* claimed;
     u8* claimedObs;
     int *qBest, *qBin, *nmatches;
+    u32* slab;                       // slabCap packed candidates per query, written by the single walk
+    int slabCap;
+    int* overflow;                   // set when some query has more candidates than a slab slot holds
     // inputs of the frame-to-frame form (reference src/ORBmatcher.cc:1533-1678)
     const u8* m4Valid;
     const float *m4U, *m4V, *m4Invz;
@@ -560,7 +570,8 @@ __global__ __launch_bounds__(256) void k_projq_candidates(DevFrame train, const 
 }
 __global__ __launch_bounds__(256) void k_projq_candidates_jobs(const ProjJob* __restrict__ jobs, int mode) {
     const ProjJob& J = jobs[blockIdx.y];
-    projq_candidates_body(J.train, J.cellStart, J.cellItems, J.trainURight, J.q, mode, J.offs, J.candIdx, J.candDist, J.counts);
+    projq_candidates_body(J.train, J.cellStart, J.cellItems, J.trainURight, J.q, mode, J.offs, J.candIdx, J.candDist, J.counts,
+                          J.slab, J.slabCap, J.overflow);
 }
 __global__ void k_m4_queries(DevFrame cur, DevFrame last, const u8* valid, const float* u, const float* v,
                              const float* invz, const float* scaleFactors, float bf, float th, int direction,
@@ -606,7 +617,8 @@ template <bool RATIO>
 __device__ __forceinline__ void projq_resolve_lds_body(u8* rsm, DevFrame train, ProjQueries q, ProjPolicy pol,
                                                         const int* __restrict__ offs, const int* __restrict__ candIdx,
                                                         const int* __restrict__ candDist, int* claimed, u8* claimedObs,
-                                                        int* qBest, int* qBin, int* nmatchesOut, int total) {
+                                                        int* qBest, int* qBin, int* nmatchesOut, int total,
+                                                        const u32* __restrict__ slab = nullptr, int slabCap = 0) {
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int counters[2];  // matches, removed
@@ -620,7 +632,14 @@ __device__ __forceinline__ void projq_resolve_lds_body(u8* rsm, DevFrame train, 
     u8* held = (u8*)(level + (RATIO ? nt : 0));
     u8* ownerObs = held + nt;                  // claimedObs[]
     u8* obs = ownerObs + nt;
-    for (int k = tid; k < total; k += 256) cand[k] = ((u32)candDist[k] << 16) | (u32)candIdx[k];
+    if (slab) {
+        for (int i = tid; i < n; i += 256) {
+            const int b0 = offs[i], c = offs[i + 1] - b0;
+            for (int pp = 0; pp < c; pp++) cand[b0 + pp] = slab[(i64)i * slabCap + pp];
+        }
+    } else {
+        for (int k = tid; k < total; k += 256) cand[k] = ((u32)candDist[k] << 16) | (u32)candIdx[k];
+    }
     for (int i = tid; i <= n; i += 256) off[i] = offs[i];
     for (int i = tid; i < nt; i += 256) {
         const int c = claimed[i];
@@ -790,11 +809,11 @@ __global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQ
 }
 // One job (frame pair) per workgroup; the dynamic LDS is sized by the host for the largest job.
 template <bool RATIO>
-__global__ __launch_bounds__(256) void k_projq_resolve_lds_jobs(const ProjJob* __restrict__ jobs, ProjPolicy pol) {
+__global__ __launch_bounds__(256) void k_projq_resolve_lds_jobs(const ProjJob* __restrict__ jobs, ProjPolicy pol, int useSlab) {
     extern __shared__ __align__(16) u8 rsm[];
     const ProjJob& J = jobs[blockIdx.x];
     projq_resolve_lds_body<RATIO>(rsm, J.train, J.q, pol, J.offs, J.candIdx, J.candDist, J.claimed, J.claimedObs, J.qBest, J.qBin,
-                                  J.nmatches, J.offs[J.q.n]);
+                                  J.nmatches, J.offs[J.q.n], useSlab ? J.slab : nullptr, J.slabCap);
 }
 __global__ __launch_bounds__(64) void k_projq_resolve_jobs(const ProjJob* __restrict__ jobs, ProjPolicy pol) {
     const ProjJob& J = jobs[blockIdx.x];
@@ -1753,7 +1772,7 @@ enum {
     SL_ST_U, SL_ST_D, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, SL_BW_VALID1,
     SL_BW_VALID2, SL_BW_M12, SL_BW_M21, SL_BW_BIN, SL_BW_HIST, SL_BW_UR1, SL_BW_UR2, SL_WB_LEVEL, SL_WB_IDX, SL_WB_DIST,
     SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2, SL_DD_DESC, SL_DD_START, SL_DD_BEST, SL_DD_MED, SL_DD_OUT,
-    SL_MK_MASK, SL_MK_KPS, SL_MK_DESC, SL_RC_REC, SL_RC_IDX, SL_JB_JOBS, SL_JB_I32, SL_JB_U8, SL_JB_TOT, SL_JB_SF
+    SL_MK_MASK, SL_MK_KPS, SL_MK_DESC, SL_RC_REC, SL_RC_IDX, SL_JB_JOBS, SL_JB_I32, SL_JB_U8, SL_JB_TOT, SL_JB_SF, SL_JB_SLAB
 };
 
 // Device view of a caller array: the pointer itself for device memory, else a staged copy.
@@ -2273,10 +2292,20 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     void *dJobs, *dWords, *dBytes, *dTot, *dSf;
     if ((rc = pool_get(m, SL_JB_JOBS, (size_t)npairs * sizeof(ProjJob), &dJobs)) ||
         (rc = pool_get(m, SL_JB_I32, words * 4, &dWords)) || (rc = pool_get(m, SL_JB_U8, bytes, &dBytes)) ||
-        (rc = pool_get(m, SL_JB_TOT, (size_t)npairs * 2 * sizeof(int), &dTot)) ||
+        (rc = pool_get(m, SL_JB_TOT, ((size_t)npairs * 2 + 8) * sizeof(int), &dTot)) ||
         (rc = pool_get(m, SL_JB_SF, ORBM_MAX_LEVELS * sizeof(float), &dSf)))
         return rc;
     ORBX_HIP_CHECK(hipMemcpyAsync(dSf, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    // One walk per query when no query has more than SLAB_CAP candidates (the rule for projected
+    // searches): candidates land in a fixed slot per query and the claim resolution packs them into LDS.
+    const int SLAB_CAP = 32;
+    size_t slabWords = 0;
+    for (int i = 0; i < npairs; i++) slabWords += (size_t)pairs[i].last.n * SLAB_CAP;
+    void* dSlab;
+    if ((rc = pool_get(m, SL_JB_SLAB, std::max(slabWords, (size_t)1) * 4, &dSlab))) return rc;
+    int* dOverflow = (int*)dTot + 2 * (size_t)npairs;
+    ORBX_HIP_CHECK(hipMemsetAsync(dOverflow, 0, sizeof(int), m->stream));
+    size_t slabOff = 0;
     m->jobsHost.resize((size_t)npairs * sizeof(ProjJob));
     ProjJob* jobs = reinterpret_cast<ProjJob*>(m->jobsHost.data());
     int* wp = (int*)dWords;
@@ -2316,6 +2345,10 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
         J.claimedObs = P.cur_claimed_obs;
         J.qBest = P.query_best ? (int*)P.query_best : ownBest;
         J.nmatches = nmArr + i;
+        J.slab = (u32*)dSlab + slabOff;
+        J.slabCap = SLAB_CAP;
+        J.overflow = dOverflow;
+        slabOff += (size_t)nl * SLAB_CAP;
         J.m4Valid = P.valid;
         J.m4U = P.u;
         J.m4V = P.v;
@@ -2341,13 +2374,33 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     if (maxNl > 0) {
         hipLaunchKernelGGL(k_m4_queries_jobs, dim3((maxNl + 255) / 256, npairs), dim3(256), 0, m->stream, dJ, (const float*)dSf, bf,
                            th);
-        hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, 0);
+        hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, 3);
     }
     hipLaunchKernelGGL(k_scan_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ, (int*)dTot);
     ORBX_HIP_CHECK(hipGetLastError());
     m->totalsHost.resize((size_t)npairs);
+    int overflow = 0;
     ORBX_HIP_CHECK(hipMemcpyAsync(m->totalsHost.data(), dTot, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    ORBX_HIP_CHECK(hipMemcpyAsync(&overflow, dOverflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
     ORBX_HIP_CHECK(sync_deliver(m));
+    ProjPolicy pol = {0, TH_HIGH, 0, 0.f, check_orientation};
+    size_t maxLds = 0;
+    bool fits = true;
+    for (int i = 0; i < npairs; i++) {
+        const size_t tot = (size_t)m->totalsHost[i], nq = (size_t)pairs[i].last.n, nt = (size_t)pairs[i].cur.n;
+        maxLds = std::max(maxLds, tot * 4 + (nq + 1) * 4 + nt * 10 + nq + 16);
+        fits = fits && tot < 65536 && nt <= 65536;
+    }
+    fits = fits && maxLds <= 150 * 1024;
+    if (fits && !m->resolveJobsLdsReady) {
+        ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds_jobs<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        m->resolveJobsLdsReady = true;
+    }
+    const bool oneWalk = fits && !overflow;
+    if (oneWalk) {
+        hipLaunchKernelGGL(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, 1);
+    } else {
     size_t total = 0;
     for (int i = 0; i < npairs; i++) total += (size_t)m->totalsHost[i];
     void *cIdx, *cDist;
@@ -2362,23 +2415,9 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     }
     ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
     if (maxNl > 0) hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, 2);
-    ProjPolicy pol = {0, TH_HIGH, 0, 0.f, check_orientation};
-    // every job resolved from LDS when the largest one fits (see k_projq_resolve_lds)
-    size_t maxLds = 0;
-    bool fits = true;
-    for (int i = 0; i < npairs; i++) {
-        const size_t tot = (size_t)m->totalsHost[i], nq = (size_t)pairs[i].last.n, nt = (size_t)pairs[i].cur.n;
-        maxLds = std::max(maxLds, tot * 4 + (nq + 1) * 4 + nt * 10 + nq + 16);
-        fits = fits && tot < 65536 && nt <= 65536;
-    }
-    if (fits && maxLds <= 150 * 1024) {
-        if (!m->resolveJobsLdsReady) {
-            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds_jobs<false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            m->resolveJobsLdsReady = true;
-        }
-        hipLaunchKernelGGL(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol);
-    } else {
+    if (fits)
+        hipLaunchKernelGGL(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, 0);
+    else
         hipLaunchKernelGGL(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
     }
     ORBX_HIP_CHECK(hipGetLastError());

@@ -349,7 +349,8 @@ def test_search_by_projection_frames_with_map_point_descriptors(oracle, frames):
     m.close()
 
 
-def test_search_by_projection_batch_equals_oracle_per_pair(oracle, frames):
+@pytest.mark.parametrize("th", [40.0, 15.0, 4.0])   # with and without queries of more than 32 candidates
+def test_search_by_projection_batch_equals_oracle_per_pair(oracle, frames, th):
     """Many independent frame pairs in one call (device-resident): every pair must equal the
     oracle's result for that pair, including pairs with empty frames, other directions, map-point
     descriptors and prior claims."""
@@ -357,7 +358,7 @@ def test_search_by_projection_batch_equals_oracle_per_pair(oracle, frames):
     from slam_amd.matcher import ORBmatcher
     (ka, da), (kb, db) = frames["a"], frames["b"]
     sf = frames["sf"]
-    bf, th = 40.0, 15.0
+    bf = 40.0
     cases = []
     for i in range(9):
         valid, u, v, invz, has_obs, ur = projection_inputs(frames, 100 + i)
