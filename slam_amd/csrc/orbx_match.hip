@@ -606,13 +606,12 @@ __device__ __forceinline__ u32 wave_min_u32_dpp(u32 v) {
 //   1. every pending lane scans its candidates exactly as the reference's loop does, against the state
 //      left by everything committed so far;
 //   2. lanes publish the keypoint they would claim (LDS atomic min of the lane number), and a lane
-//      whose candidate list contains a keypoint published by an EARLIER pending lane is "dirty";
-//   3. all pending lanes below the lowest dirty one commit: none of their candidates is touched by an
-//      earlier uncommitted query, so what they computed is what the sequential order gives, and no two
-//      of them claim the same keypoint; the rest repeat from 1 against the new state.
-// The lowest pending lane is never dirty, so every round commits at least one query; with the handful
-// of candidates a projected query has, conflicts inside 64 queries are rare and a chunk takes a few
-// rounds.  Claims live in LDS and are written back once at the end.
+//      whose best or second-best candidate was published by an EARLIER pending lane is "dirty";
+//   3. all pending lanes below the lowest dirty one commit: neither candidate their outcome rests on is
+//      touched by an earlier uncommitted query, so what they computed is what the sequential order
+//      gives, and no two of them claim the same keypoint; the rest repeat from 1 against the new state.
+// The lowest pending lane is never dirty, so every round commits at least one query; two queries among
+// 64 wanting the same keypoint is rare, and a chunk takes one or two rounds.  Claims live in LDS and are written back once at the end.
 template <bool RATIO>
 __device__ __forceinline__ void projq_resolve_lds_body(u8* rsm, DevFrame train, ProjQueries q, ProjPolicy pol,
                                                         const int* __restrict__ offs, const int* __restrict__ candIdx,
@@ -670,6 +669,7 @@ __device__ __forceinline__ void projq_resolve_lds_body(u8* rsm, DevFrame train, 
             while (pending) {
                 const bool mine = (pending >> lane) & 1ull;
                 int result = -1;
+                int depBest = -1, depSecond = -1;  // the only two candidates the outcome depends on
                 {
                     // Keys (distance << 16 | position) of the candidates that are not held; the reference's
                     // strict '<' scan from 256 keeps the first minimum, i.e. the smallest key.  Its second
@@ -699,6 +699,7 @@ __device__ __forceinline__ void projq_resolve_lds_body(u8* rsm, DevFrame train, 
                         for (int j = 1; j < RCACHE; j++) bw = bestPos == j ? cw[j] : bw;
                         if (bestPos >= RCACHE) bw = cand[b + bestPos];
                         result = (int)(bw & 0xFFFFu);
+                        depBest = result;
                         if (RATIO) {
                             u32 kp = 0xFFFFFFFFu, kq = 0xFFFFFFFFu;
 #pragma unroll
@@ -718,11 +719,13 @@ __device__ __forceinline__ void projq_resolve_lds_body(u8* rsm, DevFrame train, 
                             int second = 256, level2 = -1;
                             if (kp != 0xFFFFFFFFu && (int)(kp >> 16) < 256) {
                                 second = (int)(kp >> 16);
-                                level2 = level[cand[b + (int)(kp & 0xFFFFu)] & 0xFFFFu];
+                                depSecond = (int)(cand[b + (int)(kp & 0xFFFFu)] & 0xFFFFu);
+                                level2 = level[depSecond];
                             }
                             if (kq != 0xFFFFFFFFu && (int)(kq >> 16) < second) {
                                 second = (int)(kq >> 16);
-                                level2 = level[cand[b + (int)(kq & 0xFFFFu)] & 0xFFFFu];
+                                depSecond = (int)(cand[b + (int)(kq & 0xFFFFu)] & 0xFFFFu);
+                                level2 = level[depSecond];
                             }
                             if (level[result] == level2 && (float)bestDist > __fmul_rn(pol.nnRatio, (float)second)) result = -1;
                         }
@@ -730,15 +733,12 @@ __device__ __forceinline__ void projq_resolve_lds_body(u8* rsm, DevFrame train, 
                 }
                 const bool wants = mine && result >= 0;
                 if (wants) atomicMin(&first[result], (u32)lane);
-                bool dirty = false;
-                if (mine) {
-                    u32 fl[RCACHE];
-#pragma unroll
-                    for (int j = 0; j < RCACHE; j++) fl[j] = b + j < e ? first[cw[j] & 0xFFFFu] : 0xFFFFFFFFu;
-#pragma unroll
-                    for (int j = 0; j < RCACHE; j++) dirty |= fl[j] < (u32)lane;
-                    for (int k = b + RCACHE; k < e; k++) dirty |= first[cand[k] & 0xFFFFu] < (u32)lane;
-                }
+                // A claim by an earlier query only removes a candidate from this one's list.  Removing a
+                // candidate that is neither the best nor the second best the scan settled on leaves both as
+                // they are (each is a minimum over its side of the list), so those two are the whole dependency.
+                const u32 fa = depBest >= 0 ? first[depBest] : 0xFFFFFFFFu;
+                const u32 fb = depSecond >= 0 ? first[depSecond] : 0xFFFFFFFFu;
+                const bool dirty = mine && min(fa, fb) < (u32)lane;
                 if (wants) first[result] = 0xFFFFFFFFu;  // leave the table clean for the next round
                 const u64 dm = __ballot(mine && dirty);
                 const int d = dm ? __ffsll((unsigned long long)dm) - 1 : 64;
