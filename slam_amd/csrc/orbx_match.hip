@@ -196,6 +196,75 @@ __device__ __forceinline__ int walk_window(const DevFrame& f, const int* __restr
     return count;
 }
 
+// The same walk with 16 lanes per query, four queries to a wave, for windows of a few cells (a
+// frame-to-frame search at th 7..15 sees a dozen keypoints in its cell rectangle: one query per wave
+// leaves 60 lanes idle behind four dependent loads per grid column).  The columns' CSR runs are
+// concatenated (prefix sum over the columns, 16 at a time), so one trip takes 16 items across all
+// columns in window order.  All 64 lanes stay in the loops (the shuffles and ballots need them);
+// `active` masks a group without a query.
+template <typename Emit>
+__device__ __forceinline__ int walk_window_g16(const DevFrame& f, const int* __restrict__ cellStart,
+                                               const int* __restrict__ cellItems, const float* __restrict__ uRight,
+                                               const Query& q, bool active, Emit emit) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, shift = lane & 48;
+    Window w = window_cells(f, q.x, q.y, q.r);
+    const bool live = active && !w.empty;
+    const int ncols = live ? w.x1 - w.x0 + 1 : 0;
+    const bool checkLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
+    int count = 0;
+    for (int c0 = 0; __any(c0 < ncols); c0 += 16) {
+        const int c = c0 + sub;
+        int b = 0, len = 0;
+        if (c < ncols) {
+            b = cellStart[(w.x0 + c) * GRID_ROWS + w.y0];
+            len = cellStart[(w.x0 + c) * GRID_ROWS + w.y1 + 1] - b;
+        }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int t = __shfl_up(incl, o, 16);
+            if (sub >= o) incl += t;
+        }
+        const int total = __shfl(incl, 15, 16);
+        for (int t0 = 0; __any(t0 < total); t0 += 16) {
+            const int t = t0 + sub;
+            // column of item t = number of columns whose run ends at or before t
+            int col = 0;
+            for (int j = 0; j < 16; j++) {
+                if (!__any(c0 + j < ncols)) break;
+                col += __shfl(incl, j, 16) <= t ? 1 : 0;
+            }
+            col = min(col, 15);
+            const int bcol = __shfl(b, col, 16);
+            const int ecol = __shfl(incl - len, col, 16);
+            bool ok = false;
+            int idx = -1;
+            if (t < total) {
+                idx = cellItems[bcol + (t - ecol)];
+                const orbx_keypoint kp = f.kps[idx];
+                ok = true;
+                if (checkLevels) {
+                    if (kp.octave < q.minLevel) ok = false;
+                    if (q.maxLevel >= 0 && kp.octave > q.maxLevel) ok = false;
+                }
+                const float dx = __fsub_rn(kp.x, q.x), dy = __fsub_rn(kp.y, q.y);
+                if (!(fabsf(dx) < q.r && fabsf(dy) < q.r)) ok = false;
+                if (ok && q.useRight) {
+                    const float urk = uRight[idx];
+                    if (urk > 0) {
+                        const float er = fabsf(__fsub_rn(q.ur, urk));
+                        if (er > q.rGate) ok = false;
+                    }
+                }
+            }
+            const u32 gm = (u32)(__ballot(ok) >> shift) & 0xFFFFu;
+            if (ok) emit(count + __popc(gm & ((1u << sub) - 1u)), idx);
+            count += __popc(gm);
+        }
+    }
+    return count;
+}
+
 __device__ __forceinline__ int desc_distance(const u8* a, const u8* b) {
     const uint4* pa = (const uint4*)a;
     const uint4* pb = (const uint4*)b;
@@ -333,6 +402,37 @@ __device__ __forceinline__ void projq_candidates_body(DevFrame train, const int*
         });
     }
     if ((threadIdx.x & 63) == 0 && (mode == 0 || mode == 3)) {
+        counts[i] = n;
+        if (mode == 3 && n > slabCap) atomicOr(overflow, 1);
+    }
+}
+
+// Sixteen lanes per query; same outputs as projq_candidates_body.
+__device__ __forceinline__ void projq_candidates_g16_body(DevFrame train, const int* __restrict__ cellStart,
+                                                          const int* __restrict__ cellItems,
+                                                          const float* __restrict__ trainURight, ProjQueries q, int mode,
+                                                          const int* __restrict__ offs, int* candIdx, int* candDist,
+                                                          int* counts, u32* slab, int slabCap, int* overflow) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    Query qq;
+    qq.x = qq.y = 0.f;
+    qq.r = -1.f;
+    qq.minLevel = qq.maxLevel = -1;
+    qq.useRight = false;
+    qq.ur = qq.rGate = 0.f;
+    const bool inRange = i < q.n;
+    const bool active = inRange && projq_query(q, i, &qq);
+    const u8* qd = q.desc + (i64)(inRange ? i : 0) * 32;
+    const i64 rowBase = (mode == 2 && inRange) ? offs[i] : 0;
+    const int n = walk_window_g16(train, cellStart, cellItems, trainURight, qq, active, [&](int pos, int idx) {
+        if (mode == 2) {
+            candIdx[rowBase + pos] = idx;
+            candDist[rowBase + pos] = desc_distance(qd, train.desc + (i64)idx * 32);
+        } else if (mode == 3 && pos < slabCap) {
+            slab[(i64)i * slabCap + pos] = ((u32)desc_distance(qd, train.desc + (i64)idx * 32) << 16) | (u32)idx;
+        }
+    });
+    if (inRange && (threadIdx.x & 15) == 0 && (mode == 0 || mode == 3)) {
         counts[i] = n;
         if (mode == 3 && n > slabCap) atomicOr(overflow, 1);
     }
@@ -572,6 +672,12 @@ __global__ __launch_bounds__(256) void k_projq_candidates_jobs(const ProjJob* __
     const ProjJob& J = jobs[blockIdx.y];
     projq_candidates_body(J.train, J.cellStart, J.cellItems, J.trainURight, J.q, mode, J.offs, J.candIdx, J.candDist, J.counts,
                           J.slab, J.slabCap, J.overflow);
+}
+__global__ __launch_bounds__(256) void k_projq_candidates_jobs_g16(const ProjJob* __restrict__ jobs, int mode) {
+    const ProjJob& J = jobs[blockIdx.y];
+    if ((int)blockIdx.x * 16 >= J.q.n) return;
+    projq_candidates_g16_body(J.train, J.cellStart, J.cellItems, J.trainURight, J.q, mode, J.offs, J.candIdx, J.candDist,
+                              J.counts, J.slab, J.slabCap, J.overflow);
 }
 __global__ void k_m4_queries(DevFrame cur, DevFrame last, const u8* valid, const float* u, const float* v,
                              const float* invz, const float* scaleFactors, float bf, float th, int direction,
@@ -2371,10 +2477,18 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
     const ProjJob* dJ = (const ProjJob*)dJobs;
     hipLaunchKernelGGL(k_grid_build_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ);
+    // windows of a few grid cells (radius th * scale factor of the level) go four queries to a wave
+    const bool smallWindows = th <= 15.f;
+    auto launch_candidates = [&](int mode) {
+        if (smallWindows)
+            hipLaunchKernelGGL(k_projq_candidates_jobs_g16, dim3((maxNl + 15) / 16, npairs), dim3(256), 0, m->stream, dJ, mode);
+        else
+            hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, mode);
+    };
     if (maxNl > 0) {
         hipLaunchKernelGGL(k_m4_queries_jobs, dim3((maxNl + 255) / 256, npairs), dim3(256), 0, m->stream, dJ, (const float*)dSf, bf,
                            th);
-        hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, 3);
+        launch_candidates(3);
     }
     hipLaunchKernelGGL(k_scan_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ, (int*)dTot);
     ORBX_HIP_CHECK(hipGetLastError());
@@ -2414,7 +2528,7 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
         off += (size_t)m->totalsHost[i];
     }
     ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
-    if (maxNl > 0) hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, 2);
+    if (maxNl > 0) launch_candidates(2);
     if (fits)
         hipLaunchKernelGGL(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, 0);
     else
