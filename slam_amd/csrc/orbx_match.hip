@@ -1833,7 +1833,6 @@ struct orbm_context {
     hipStream_t ownStream = nullptr, stream = nullptr;
     // grow-only scratch, one block per purpose
     std::vector<std::pair<void*, size_t>> pool;
-    std::vector<unsigned char> jobsHost;  // host image of the job table of a batched call
     std::vector<int> totalsHost;
     bool resolveLdsReady = false, resolveJobsLdsReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
     // Host arrays travel through one pinned arena per call: copies from and to pageable memory are staged
@@ -2401,7 +2400,7 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
         (rc = pool_get(m, SL_JB_TOT, ((size_t)npairs * 2 + 8) * sizeof(int), &dTot)) ||
         (rc = pool_get(m, SL_JB_SF, ORBM_MAX_LEVELS * sizeof(float), &dSf)))
         return rc;
-    ORBX_HIP_CHECK(hipMemcpyAsync(dSf, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    if ((rc = h2d(m, dSf, scale_factors, (size_t)nlevels * sizeof(float)))) return rc;
     // One walk per query when no query has more than SLAB_CAP candidates (the rule for projected
     // searches): candidates land in a fixed slot per query and the claim resolution packs them into LDS.
     const int SLAB_CAP = 32;
@@ -2412,8 +2411,9 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     int* dOverflow = (int*)dTot + 2 * (size_t)npairs;
     ORBX_HIP_CHECK(hipMemsetAsync(dOverflow, 0, sizeof(int), m->stream));
     size_t slabOff = 0;
-    m->jobsHost.resize((size_t)npairs * sizeof(ProjJob));
-    ProjJob* jobs = reinterpret_cast<ProjJob*>(m->jobsHost.data());
+    // the job table is built in pinned memory, so its upload is one asynchronous copy
+    ProjJob* jobs = (ProjJob*)arena_alloc(m, (size_t)npairs * sizeof(ProjJob));
+    if (!jobs) return ORBX_ERR_HIP;
     int* wp = (int*)dWords;
     u8* bp = (u8*)dBytes;
     int* nmArr = (int*)dTot + npairs;
@@ -2494,8 +2494,8 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     ORBX_HIP_CHECK(hipGetLastError());
     m->totalsHost.resize((size_t)npairs);
     int overflow = 0;
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->totalsHost.data(), dTot, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    ORBX_HIP_CHECK(hipMemcpyAsync(&overflow, dOverflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if ((rc = d2h(m, m->totalsHost.data(), dTot, (size_t)npairs * sizeof(int))) || (rc = d2h(m, &overflow, dOverflow, sizeof(int))))
+        return rc;
     ORBX_HIP_CHECK(sync_deliver(m));
     ProjPolicy pol = {0, TH_HIGH, 0, 0.f, check_orientation};
     size_t maxLds = 0;
@@ -2535,7 +2535,7 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
         hipLaunchKernelGGL(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
     }
     ORBX_HIP_CHECK(hipGetLastError());
-    ORBX_HIP_CHECK(hipMemcpyAsync(m->totalsHost.data(), nmArr, (size_t)npairs * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    if ((rc = d2h(m, m->totalsHost.data(), nmArr, (size_t)npairs * sizeof(int)))) return rc;
     ORBX_HIP_CHECK(sync_deliver(m));
     for (int i = 0; i < npairs; i++) pairs[i].nmatches = m->totalsHost[i];
     return ORBX_OK;
