@@ -1027,6 +1027,177 @@ __global__ __launch_bounds__(64) void k_init_resolve(DevFrame f1, DevFrame f2, c
     if (lane == 0) *nmatchesOut = nmatches;
 }
 
+// Candidate rows sorted by (distance, position in the row): sorted[b + rank] = distance << 16 | index.
+// One wave per query; the rank of an entry is the number of smaller keys in its row (keys are unique).
+// With a row in this order the reference's scan (src/ORBmatcher.cc:529-548) reads off its result from
+// the front: the best is the first admissible entry, the second-best distance that of the next one.
+__global__ __launch_bounds__(256) void k_sort_rows(const int* __restrict__ offs, const int* __restrict__ candIdx,
+                                                    const int* __restrict__ candDist, u32* __restrict__ sorted, int nq) {
+    __shared__ u32 rows[4][1024];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= nq) return;
+    u32* row = rows[wv];
+    const int b = offs[q], n = offs[q + 1] - b;
+    if (n <= 0) return;
+    auto keyAt = [&](int k) { return ((u32)candDist[b + k] << 16) | (u32)(k & 0xFFFF); };
+    const bool small = n <= 1024;
+    if (small)
+        for (int k = lane; k < n; k += 64) row[k] = keyAt(k);
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int j = t0 + lane;
+        const u32 myKey = j < n ? keyAt(j) : 0xFFFFFFFFu;
+        int rank = 0;
+        if (small) {
+#pragma unroll 4
+            for (int k = 0; k < n; k++) rank += row[k] < myKey ? 1 : 0;
+        } else {
+            // rows longer than the staging buffer go through it tile by tile; positions wrap at 65536
+            // only for rows no frame of 65000 keypoints can produce
+            for (int tile0 = 0; tile0 < n; tile0 += 1024) {
+                const int m = min(1024, n - tile0);
+                for (int k = lane; k < m; k += 64) row[k] = keyAt(tile0 + k);
+                for (int k = 0; k < m; k++) rank += row[k] < myKey ? 1 : 0;
+            }
+        }
+        if (j < n) sorted[b + rank] = (myKey & 0xFFFF0000u) | (u32)candIdx[b + j];
+    }
+}
+
+// SearchForInitialization's sequential part over sorted rows, all state in LDS, 64 queries at a time
+// (one per lane).  A match only lowers vMatchedDistance of its target, i.e. removes that target from
+// later queries' lists, so a query depends on earlier uncommitted ones only through its best and
+// second-best entries: a lane whose best or second is wanted by an earlier pending lane waits a round,
+// all pending lanes below the lowest such lane commit together, and the result is that of the serial loop.
+__global__ __launch_bounds__(256) void k_init_resolve_sorted(DevFrame f1, DevFrame f2, const int* __restrict__ offs,
+                                                              const u32* __restrict__ sorted, float nnRatio, int checkOri,
+                                                              int* matches12, float* prevMatched, int* nmatchesOut) {
+    extern __shared__ __align__(16) u8 ism[];
+    __shared__ int hist[HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int counters[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n1 = f1.n, n2 = f2.n;
+    int* mdist = (int*)ism;          // vMatchedDistance
+    int* m21 = mdist + n2;           // vnMatches21
+    u32* first = (u32*)(m21 + n2);   // lowest pending lane that wants this keypoint in the current round
+    int* m12 = (int*)(first + n2);   // vnMatches12
+    int* qbin = m12 + n1;
+    for (int i = tid; i < n2; i += 256) {
+        mdist[i] = 0x7FFFFFFF;
+        m21[i] = -1;
+        first[i] = 0xFFFFFFFFu;
+    }
+    for (int i = tid; i < n1; i += 256) {
+        m12[i] = -1;
+        qbin[i] = -1;
+    }
+    if (tid < HISTO_LENGTH) hist[tid] = 0;
+    if (tid < 2) counters[tid] = 0;
+    __syncthreads();
+    if (tid < 64) {
+        int nmatches = 0;
+        for (int q0 = 0; q0 < n1; q0 += 64) {
+            const int i = q0 + lane;
+            const bool have = i < n1;
+            const int b = have ? offs[i] : 0, e = have ? offs[i + 1] : 0;
+            constexpr int RC = 4;
+            u32 cw[RC];
+#pragma unroll
+            for (int j = 0; j < RC; j++) cw[j] = b + j < e ? sorted[b + j] : 0xFFFFFFFFu;
+            u64 pending = __ballot(have && e > b);
+            while (pending) {
+                const bool mine = (pending >> lane) & 1ull;
+                u32 bestW = 0xFFFFFFFFu, secondW = 0xFFFFFFFFu;
+                int found = 0;
+#pragma unroll
+                for (int j = 0; j < RC; j++) {
+                    const u32 c = cw[j];
+                    const bool adm = mine && c != 0xFFFFFFFFu && mdist[c & 0xFFFFu] > (int)(c >> 16);
+                    if (adm && found == 1) {
+                        secondW = c;
+                        found = 2;
+                    }
+                    if (adm && found == 0) {
+                        bestW = c;
+                        found = 1;
+                    }
+                }
+                if (mine) {
+                    for (int k = b + RC; k < e && found < 2; k++) {
+                        const u32 c = sorted[k];
+                        if (mdist[c & 0xFFFFu] > (int)(c >> 16)) {
+                            if (found == 0) bestW = c;
+                            else secondW = c;
+                            found++;
+                        }
+                    }
+                }
+                const int bestDist = (int)(bestW >> 16);
+                const float second = found == 2 ? (float)(int)(secondW >> 16) : (float)0x7FFFFFFF;
+                const bool inReach = found >= 1 && bestDist <= TH_LOW;  // otherwise no later state can produce a match
+                const bool wants = inReach && (float)bestDist < __fmul_rn(second, nnRatio);
+                const int target = (int)(bestW & 0xFFFFu);
+                if (wants) atomicMin(&first[target], (u32)lane);
+                const u32 fa = inReach ? first[target] : 0xFFFFFFFFu;
+                const u32 fb = (inReach && found == 2) ? first[secondW & 0xFFFFu] : 0xFFFFFFFFu;
+                const bool dirty = mine && min(fa, fb) < (u32)lane;
+                if (wants) first[target] = 0xFFFFFFFFu;
+                const u64 dm = __ballot(dirty);
+                const int d = dm ? __ffsll((unsigned long long)dm) - 1 : 64;
+                const bool commit = mine && lane < d;
+                bool replaced = false;
+                if (commit && wants) {
+                    const int prev = m21[target];
+                    replaced = prev >= 0;
+                    if (replaced) m12[prev] = -1;
+                    m12[i] = target;
+                    m21[target] = i;
+                    mdist[target] = bestDist;
+                    if (checkOri) {
+                        const int bin = rot_bin(f1.kps[i].angle, f2.kps[target].angle);
+                        qbin[i] = bin;
+                        atomicAdd(&hist[bin], 1);
+                    }
+                }
+                nmatches += __popcll(__ballot(commit && wants)) - __popcll(__ballot(replaced));
+                pending &= ~__ballot(commit);
+            }
+        }
+        if (lane == 0) counters[0] = nmatches;
+    }
+    __syncthreads();
+    if (checkOri) {
+        if (tid == 0) {
+            int a = -1, b2 = -1, c = -1;
+            three_maxima(hist, HISTO_LENGTH, a, b2, c);
+            keep[0] = a;
+            keep[1] = b2;
+            keep[2] = c;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int i = tid; i < n1; i += 256) {
+            const int bin = qbin[i];
+            if (bin >= 0 && bin != keep[0] && bin != keep[1] && bin != keep[2] && m12[i] >= 0) {
+                m12[i] = -1;
+                removed++;
+            }
+        }
+        if (removed) atomicAdd(&counters[1], removed);
+        __syncthreads();
+    }
+    for (int i = tid; i < n1; i += 256) {
+        const int mt = m12[i];
+        matches12[i] = mt;
+        if (mt >= 0) {
+            prevMatched[2 * i] = f2.kps[mt].x;
+            prevMatched[2 * i + 1] = f2.kps[mt].y;
+        }
+    }
+    if (tid == 0) *nmatchesOut = counters[0] - counters[1];
+}
+
 // Queries of SearchForInitialization: level-0 keypoints of F1 search a window
 // around their previous match in F2 at level 0 (reference :515-523).
 __global__ void k_init_queries(DevFrame f1, const float* prevMatched, float window, float* qx, float* qy, float* qr,
@@ -1834,7 +2005,7 @@ struct orbm_context {
     // grow-only scratch, one block per purpose
     std::vector<std::pair<void*, size_t>> pool;
     std::vector<int> totalsHost;
-    bool resolveLdsReady = false, resolveJobsLdsReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
+    bool resolveLdsReady = false, resolveJobsLdsReady = false, initSortedReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
     // Host arrays travel through one pinned arena per call: copies from and to pageable memory are staged
     // and serialised by the runtime (10-15 us each), copies from pinned memory are plain queue entries.
     // Results land in the arena and are handed to the caller's arrays after the stream has been waited for.
@@ -1877,7 +2048,7 @@ enum {
     SL_ST_U, SL_ST_D, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, SL_BW_VALID1,
     SL_BW_VALID2, SL_BW_M12, SL_BW_M21, SL_BW_BIN, SL_BW_HIST, SL_BW_UR1, SL_BW_UR2, SL_WB_LEVEL, SL_WB_IDX, SL_WB_DIST,
     SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2, SL_DD_DESC, SL_DD_START, SL_DD_BEST, SL_DD_MED, SL_DD_OUT,
-    SL_MK_MASK, SL_MK_KPS, SL_MK_DESC, SL_RC_REC, SL_RC_IDX, SL_JB_JOBS, SL_JB_I32, SL_JB_U8, SL_JB_TOT, SL_JB_SF, SL_JB_SLAB
+    SL_MK_MASK, SL_MK_KPS, SL_MK_DESC, SL_RC_REC, SL_RC_IDX, SL_JB_JOBS, SL_JB_I32, SL_JB_U8, SL_JB_TOT, SL_JB_SF, SL_JB_SLAB, SL_SORTED
 };
 
 // Device view of a caller array: the pointer itself for device memory, else a staged copy.
@@ -2194,9 +2365,25 @@ int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const 
                        2, 0, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr);
     int* dM12;
     if ((rc = stage_out(m, SL_STATE_C, (int*)matches12, (size_t)n1, mem_space, &dM12))) return rc;
-    hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), 0, m->stream, d1, d2, (const int*)offs, (const int*)cIdx,
-                       (const int*)cDist, nn_ratio, check_orientation, (int*)sA, (int*)sB, dM12, (int*)sD, dPrev,
-                       (int*)scal);
+    const size_t ldsBytes = (size_t)n2 * 12 + (size_t)n1 * 8 + 16;
+    if (ldsBytes <= 150 * 1024 && d2.n <= 65536) {
+        // rows sorted by distance in parallel, then the serial claims 64 queries at a time from LDS
+        void* srt;
+        if ((rc = pool_get(m, SL_SORTED, (size_t)std::max(total, 1) * 4, &srt))) return rc;
+        if (!m->initSortedReady) {
+            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_init_resolve_sorted, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               150 * 1024));
+            m->initSortedReady = true;
+        }
+        hipLaunchKernelGGL(k_sort_rows, dim3((n1 + 3) / 4), dim3(256), 0, m->stream, (const int*)offs, (const int*)cIdx,
+                           (const int*)cDist, (u32*)srt, n1);
+        hipLaunchKernelGGL(k_init_resolve_sorted, dim3(1), dim3(256), ldsBytes, m->stream, d1, d2, (const int*)offs,
+                           (const u32*)srt, nn_ratio, check_orientation, dM12, dPrev, (int*)scal);
+    } else {
+        hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), 0, m->stream, d1, d2, (const int*)offs, (const int*)cIdx,
+                           (const int*)cDist, nn_ratio, check_orientation, (int*)sA, (int*)sB, dM12, (int*)sD, dPrev,
+                           (int*)scal);
+    }
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)matches12, (const int*)dM12, (size_t)n1, mem_space))) return rc;
     if ((rc = copy_back(m, prev_matched_xy, (const float*)dPrev, (size_t)n1 * 2, mem_space))) return rc;
