@@ -2012,6 +2012,13 @@ struct orbm_context {
     unsigned char* arena = nullptr;
     size_t arenaCap = 0, arenaUsed = 0;
     std::vector<void*> arenaRetired;
+    // Device mirror of the arena: an input array staged at arena offset o is read by the kernels at
+    // dArena + o, and everything staged since the last launch goes up in ONE copy just before the next
+    // launch (a call with a dozen input arrays pays one queue entry instead of a dozen).
+    unsigned char* dArena = nullptr;
+    std::vector<void*> dArenaRetired;
+    size_t upLo = 0, upHi = 0;          // staged and not uploaded yet: [upLo, upHi) of the current arena
+    hipError_t asyncError = hipSuccess;  // first failure of a deferred upload, reported by the next wait
     struct Delivery {
         void* dst;
         const void* src;
@@ -2023,6 +2030,13 @@ struct orbm_context {
 namespace {
 
 hipError_t sync_deliver(orbm_context* m);
+void flush_uploads(orbm_context* m);
+// every kernel launch of the host side goes through this: staged inputs are uploaded first
+#define ORBM_LAUNCH(...)                 \
+    do {                                 \
+        flush_uploads(m);                \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
 
 int pool_get(orbm_context* m, int slot, size_t bytes, void** out) {
     if ((int)m->pool.size() <= slot) m->pool.resize(slot + 1, std::make_pair((void*)nullptr, (size_t)0));
@@ -2058,13 +2072,22 @@ void* arena_alloc(orbm_context* m, size_t bytes) {
     if (m->arenaUsed + need > m->arenaCap) {
         // blocks handed out earlier in this call stay valid: the old arena is kept until the next call
         const size_t cap = std::max(m->arenaCap * 2, std::max(need * 2, (size_t)1 << 20));
-        void* p = nullptr;
+        flush_uploads(m);  // what is staged so far belongs to the old pair of buffers
+        void *p = nullptr, *dp = nullptr;
         if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
             orbx_set_error("hipHostMalloc of %zu bytes failed", cap);
             return nullptr;
         }
+        if (hipMalloc(&dp, cap) != hipSuccess) {
+            (void)hipHostFree(p);
+            orbx_set_error("hipMalloc of %zu bytes failed", cap);
+            return nullptr;
+        }
         if (m->arena) m->arenaRetired.push_back(m->arena);
+        if (m->dArena) m->dArenaRetired.push_back(m->dArena);
         m->arena = (unsigned char*)p;
+        m->dArena = (unsigned char*)dp;
+        m->upLo = m->upHi = 0;
         m->arenaCap = cap;
         m->arenaUsed = 0;
     }
@@ -2077,9 +2100,19 @@ void* arena_alloc(orbm_context* m, size_t bytes) {
 // sync_deliver), so the arena starts over.
 void arena_reset(orbm_context* m) {
     m->arenaUsed = 0;
+    m->upLo = m->upHi = 0;
     for (void* p : m->arenaRetired) (void)hipHostFree(p);
     m->arenaRetired.clear();
+    for (void* p : m->dArenaRetired) (void)hipFree(p);
+    m->dArenaRetired.clear();
     m->pending.clear();
+}
+
+void flush_uploads(orbm_context* m) {
+    if (m->upHi <= m->upLo) return;
+    const hipError_t e = hipMemcpyAsync(m->dArena + m->upLo, m->arena + m->upLo, m->upHi - m->upLo, hipMemcpyHostToDevice, m->stream);
+    if (e != hipSuccess && m->asyncError == hipSuccess) m->asyncError = e;
+    m->upLo = m->upHi = 0;
 }
 
 int h2d(orbm_context* m, void* dev, const void* host, size_t bytes) {
@@ -2101,8 +2134,14 @@ int d2h(orbm_context* m, void* host, const void* dev, size_t bytes) {
 }
 
 hipError_t sync_deliver(orbm_context* m) {
+    flush_uploads(m);
     const hipError_t e = hipStreamSynchronize(m->stream);
     if (e != hipSuccess) return e;
+    if (m->asyncError != hipSuccess) {
+        const hipError_t a = m->asyncError;
+        m->asyncError = hipSuccess;
+        return a;
+    }
     for (const auto& d : m->pending) memcpy(d.dst, d.src, d.bytes);
     m->pending.clear();
     return hipSuccess;
@@ -2114,11 +2153,15 @@ int stage_in(orbm_context* m, int slot, const T* src, size_t count, int memSpace
         *out = src;
         return ORBX_OK;
     }
-    void* d = nullptr;
-    int rc = pool_get(m, slot, std::max(count, (size_t)1) * sizeof(T), &d);
-    if (rc) return rc;
-    if ((rc = h2d(m, d, src, count * sizeof(T)))) return rc;
-    *out = (const T*)d;
+    (void)slot;
+    const size_t bytes = count * sizeof(T);
+    unsigned char* p = (unsigned char*)arena_alloc(m, std::max(bytes, (size_t)64));
+    if (!p) return ORBX_ERR_HIP;
+    memcpy(p, src, bytes);
+    const size_t off = (size_t)(p - m->arena);
+    if (m->upHi <= m->upLo) m->upLo = off;
+    m->upHi = off + ((bytes + 63) & ~(size_t)63);
+    *out = (const T*)(m->dArena + off);
     return ORBX_OK;
 }
 
@@ -2173,7 +2216,7 @@ int build_grid(orbm_context* m, const DevFrame& f, int** cellStart, int** cellIt
     if (rc) return rc;
     rc = pool_get(m, SL_CELL_OF, (size_t)std::max(f.n, 1) * sizeof(u16), &co);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(1024), 0, m->stream, f, (int*)cs, (int*)ci, (u16*)co);
+    ORBM_LAUNCH(k_grid_build, dim3(1), dim3(1024), 0, m->stream, f, (int*)cs, (int*)ci, (u16*)co);
     ORBX_HIP_CHECK(hipGetLastError());
     *cellStart = (int*)cs;
     *cellItems = (int*)ci;
@@ -2237,6 +2280,8 @@ void orbm_destroy(orbm_context* m) {
         if (e.first) (void)hipFree(e.first);
     for (void* p : m->arenaRetired) (void)hipHostFree(p);
     if (m->arena) (void)hipHostFree(m->arena);
+    for (void* p : m->dArenaRetired) (void)hipFree(p);
+    if (m->dArena) (void)hipFree(m->dArena);
     if (m->ownStream) (void)hipStreamDestroy(m->ownStream);
     delete m;
 }
@@ -2304,7 +2349,7 @@ int orbm_window_candidates(orbm_context* m, const orbm_frame* train, const float
     if ((rc = stage_out(m, SL_CAND_IDX, (int*)cand_idx, rows, mem_space, &dIdx))) return rc;
     if (cand_dist && (rc = stage_out(m, SL_CAND_DIST, (int*)cand_dist, rows, mem_space, &dDist))) return rc;
     if ((rc = stage_out(m, SL_COUNTS, (int*)counts, (size_t)nq, mem_space, &dCnt))) return rc;
-    hipLaunchKernelGGL(k_window, dim3((nq + 3) / 4), dim3(256), 0, m->stream, df, (const int*)cs, (const int*)ci, qa,
+    ORBM_LAUNCH(k_window, dim3((nq + 3) / 4), dim3(256), 0, m->stream, df, (const int*)cs, (const int*)ci, qa,
                        nq, 1, max_cand, (const int*)nullptr, dIdx, dDist, dCnt);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)cand_idx, dIdx, rows, mem_space))) return rc;
@@ -2348,12 +2393,12 @@ int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const 
         (rc = pool_get(m, SL_STATE_B, (size_t)n2 * 4, &sB)) || (rc = pool_get(m, SL_STATE_C, (size_t)n1 * 4, &sC)) ||
         (rc = pool_get(m, SL_STATE_D, (size_t)n1 * 4, &sD)) || (rc = pool_get(m, SL_SCALAR, 64, &scal)))
         return rc;
-    hipLaunchKernelGGL(k_init_queries, dim3((n1 + 255) / 256), dim3(256), 0, m->stream, d1, (const float*)dPrev,
+    ORBM_LAUNCH(k_init_queries, dim3((n1 + 255) / 256), dim3(256), 0, m->stream, d1, (const float*)dPrev,
                        (float)window_size, (float*)qx, (float*)qy, (float*)qr, (int*)qmin, (int*)qmax);
     QueryArrays qa = {(const float*)qx, (const float*)qy, (const float*)qr, (const int*)qmin, (const int*)qmax, d1.desc};
-    hipLaunchKernelGGL(k_window, dim3((n1 + 3) / 4), dim3(256), 0, m->stream, d2, (const int*)cs, (const int*)ci, qa, n1,
+    ORBM_LAUNCH(k_window, dim3((n1 + 3) / 4), dim3(256), 0, m->stream, d2, (const int*)cs, (const int*)ci, qa, n1,
                        0, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, n1);
+    ORBM_LAUNCH(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, n1);
     int total = 0;
     if ((rc = d2h(m, &total, (int*)offs + n1, sizeof(int)))) return rc;
     ORBX_HIP_CHECK(sync_deliver(m));
@@ -2361,7 +2406,7 @@ int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const 
     if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
         (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
         return rc;
-    hipLaunchKernelGGL(k_window, dim3((n1 + 3) / 4), dim3(256), 0, m->stream, d2, (const int*)cs, (const int*)ci, qa, n1,
+    ORBM_LAUNCH(k_window, dim3((n1 + 3) / 4), dim3(256), 0, m->stream, d2, (const int*)cs, (const int*)ci, qa, n1,
                        2, 0, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr);
     int* dM12;
     if ((rc = stage_out(m, SL_STATE_C, (int*)matches12, (size_t)n1, mem_space, &dM12))) return rc;
@@ -2375,12 +2420,12 @@ int orbm_search_for_initialization(orbm_context* m, const orbm_frame* f1, const 
                                                150 * 1024));
             m->initSortedReady = true;
         }
-        hipLaunchKernelGGL(k_sort_rows, dim3((n1 + 3) / 4), dim3(256), 0, m->stream, (const int*)offs, (const int*)cIdx,
+        ORBM_LAUNCH(k_sort_rows, dim3((n1 + 3) / 4), dim3(256), 0, m->stream, (const int*)offs, (const int*)cIdx,
                            (const int*)cDist, (u32*)srt, n1);
-        hipLaunchKernelGGL(k_init_resolve_sorted, dim3(1), dim3(256), ldsBytes, m->stream, d1, d2, (const int*)offs,
+        ORBM_LAUNCH(k_init_resolve_sorted, dim3(1), dim3(256), ldsBytes, m->stream, d1, d2, (const int*)offs,
                            (const u32*)srt, nn_ratio, check_orientation, dM12, dPrev, (int*)scal);
     } else {
-        hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), 0, m->stream, d1, d2, (const int*)offs, (const int*)cIdx,
+        ORBM_LAUNCH(k_init_resolve, dim3(1), dim3(64), 0, m->stream, d1, d2, (const int*)offs, (const int*)cIdx,
                            (const int*)cDist, nn_ratio, check_orientation, (int*)sA, (int*)sB, dM12, (int*)sD, dPrev,
                            (int*)scal);
     }
@@ -2412,9 +2457,9 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
     if ((rc = pool_get(m, SL_COUNTS, (size_t)nq * 4, &cnt)) || (rc = pool_get(m, SL_OFFS, (size_t)(nq + 1) * 4, &offs)) ||
         (rc = pool_get(m, SL_STATE_D, (size_t)nq * 4, &qn)) || (rc = pool_get(m, SL_SCALAR, 64, &scal)))
         return rc;
-    hipLaunchKernelGGL(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
+    ORBM_LAUNCH(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
                        dTrainURight, q, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, nq);
+    ORBM_LAUNCH(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, nq);
     int total = 0;
     if ((rc = d2h(m, &total, (int*)offs + nq, sizeof(int)))) return rc;
     ORBX_HIP_CHECK(sync_deliver(m));
@@ -2422,7 +2467,7 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
     if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
         (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
         return rc;
-    hipLaunchKernelGGL(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
+    ORBM_LAUNCH(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
                        dTrainURight, q, 2, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr);
     int* dClaim;
     u8* dClaimObs;
@@ -2455,10 +2500,10 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
             m->resolveLdsReady = true;
         }
         auto kr = pol.ratioTest ? k_projq_resolve_lds<true> : k_projq_resolve_lds<false>;
-        hipLaunchKernelGGL(kr, dim3(1), dim3(256), ldsBytes, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
+        ORBM_LAUNCH(kr, dim3(1), dim3(256), ldsBytes, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
                            (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal, total);
     } else {
-        hipLaunchKernelGGL(k_projq_resolve, dim3(1), dim3(64), 0, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
+        ORBM_LAUNCH(k_projq_resolve, dim3(1), dim3(64), 0, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
                            (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal);
     }
     ORBX_HIP_CHECK(hipGetLastError());
@@ -2536,7 +2581,7 @@ int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm
         return rc;
     ORBX_HIP_CHECK(hipMemcpyAsync(sf, scale_factors, (size_t)nlevels * sizeof(float), hipMemcpyDefault, m->stream));
     if (nl > 0)
-        hipLaunchKernelGGL(k_m4_queries, dim3((nl + 255) / 256), dim3(256), 0, m->stream, dc, dl, dValid, dU, dV, dInvz,
+        ORBM_LAUNCH(k_m4_queries, dim3((nl + 255) / 256), dim3(256), 0, m->stream, dc, dl, dValid, dU, dV, dInvz,
                            (const float*)sf, bf, th, direction, (u8*)qv, (float*)qr, (int*)qmin, (int*)qmax, (float*)qa,
                            (float*)qur);
     ProjQueries dq;
@@ -2663,21 +2708,21 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     const size_t jobBytes = (size_t)npairs * sizeof(ProjJob);
     ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
     const ProjJob* dJ = (const ProjJob*)dJobs;
-    hipLaunchKernelGGL(k_grid_build_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ);
+    ORBM_LAUNCH(k_grid_build_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ);
     // windows of a few grid cells (radius th * scale factor of the level) go four queries to a wave
     const bool smallWindows = th <= 15.f;
     auto launch_candidates = [&](int mode) {
         if (smallWindows)
-            hipLaunchKernelGGL(k_projq_candidates_jobs_g16, dim3((maxNl + 15) / 16, npairs), dim3(256), 0, m->stream, dJ, mode);
+            ORBM_LAUNCH(k_projq_candidates_jobs_g16, dim3((maxNl + 15) / 16, npairs), dim3(256), 0, m->stream, dJ, mode);
         else
-            hipLaunchKernelGGL(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, mode);
+            ORBM_LAUNCH(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, mode);
     };
     if (maxNl > 0) {
-        hipLaunchKernelGGL(k_m4_queries_jobs, dim3((maxNl + 255) / 256, npairs), dim3(256), 0, m->stream, dJ, (const float*)dSf, bf,
+        ORBM_LAUNCH(k_m4_queries_jobs, dim3((maxNl + 255) / 256, npairs), dim3(256), 0, m->stream, dJ, (const float*)dSf, bf,
                            th);
         launch_candidates(3);
     }
-    hipLaunchKernelGGL(k_scan_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ, (int*)dTot);
+    ORBM_LAUNCH(k_scan_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ, (int*)dTot);
     ORBX_HIP_CHECK(hipGetLastError());
     m->totalsHost.resize((size_t)npairs);
     int overflow = 0;
@@ -2700,7 +2745,7 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     }
     const bool oneWalk = fits && !overflow;
     if (oneWalk) {
-        hipLaunchKernelGGL(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, 1);
+        ORBM_LAUNCH(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, 1);
     } else {
     size_t total = 0;
     for (int i = 0; i < npairs; i++) total += (size_t)m->totalsHost[i];
@@ -2717,9 +2762,9 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
     if (maxNl > 0) launch_candidates(2);
     if (fits)
-        hipLaunchKernelGGL(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, 0);
+        ORBM_LAUNCH(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, 0);
     else
-        hipLaunchKernelGGL(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
+        ORBM_LAUNCH(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
     }
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = d2h(m, m->totalsHost.data(), nmArr, (size_t)npairs * sizeof(int)))) return rc;
@@ -2790,13 +2835,13 @@ int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const o
     if ((rc = stage_out(m, SL_ST_U, u_right, (size_t)dl.n, mem_space, &dU))) return rc;
     if ((rc = stage_out(m, SL_ST_D, depth, (size_t)dl.n, mem_space, &dD))) return rc;
     if (dr.n) {
-        hipLaunchKernelGGL(k_stereo_rows, dim3((dr.n + 255) / 256), dim3(256), 0, m->stream, dr, sp, (int4*)dRows);
+        ORBM_LAUNCH(k_stereo_rows, dim3((dr.n + 255) / 256), dim3(256), 0, m->stream, dr, sp, (int4*)dRows);
         ORBX_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_stereo_match, dim3((dl.n + 3) / 4), dim3(256), 0, m->stream, dl, dr, (const int4*)dRows, pl, pr, sp,
+    ORBM_LAUNCH(k_stereo_match, dim3((dl.n + 3) / 4), dim3(256), 0, m->stream, dl, dr, (const int4*)dRows, pl, pr, sp,
                        dU, dD, (int*)dSad);
     ORBX_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_stereo_median, dim3(1), dim3(1024), 0, m->stream, dl.n, (const int*)dSad, dU, dD, (int*)dKept);
+    ORBM_LAUNCH(k_stereo_median, dim3(1), dim3(1024), 0, m->stream, dl.n, (const int*)dSad, dU, dD, (int*)dKept);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, u_right, (const float*)dU, (size_t)dl.n, mem_space))) return rc;
     if ((rc = copy_back(m, depth, (const float*)dD, (size_t)dl.n, mem_space))) return rc;
@@ -2873,12 +2918,12 @@ int orbm_search_by_bow(orbm_context* m, const orbm_frame* f1, const orbm_feature
     if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dBin, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
     ORBX_HIP_CHECK(hipMemsetAsync(dHist, 0, (HISTO_LENGTH + 2) * sizeof(int), m->stream));
     if (v1.nNodes > 0 && v2.nNodes > 0 && d1.n > 0 && d2.n > 0) {
-        hipLaunchKernelGGL(k_bow_match, dim3(v1.nNodes), dim3(64), 0, m->stream, d1, v1, dValid1, d2, v2, dValid2, max_dist,
+        ORBM_LAUNCH(k_bow_match, dim3(v1.nNodes), dim3(64), 0, m->stream, d1, v1, dValid1, d2, v2, dValid2, max_dist,
                            nn_ratio, check_orientation, dM12, dM21, (int*)dBin, (int*)dHist);
         ORBX_HIP_CHECK(hipGetLastError());
     }
     int* dCount = (int*)dHist + HISTO_LENGTH;
-    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, m->stream, d1.n, check_orientation, dM12, dM21, (const int*)dBin,
+    ORBM_LAUNCH(k_bow_finish, dim3(1), dim3(256), 0, m->stream, d1.n, check_orientation, dM12, dM21, (const int*)dBin,
                        (const int*)dHist, dCount);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
@@ -2936,12 +2981,12 @@ int orbm_search_for_triangulation(orbm_context* m, const orbm_frame* f1, const o
     if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dBin, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
     ORBX_HIP_CHECK(hipMemsetAsync(dHist, 0, (HISTO_LENGTH + 2) * sizeof(int), m->stream));
     if (v1.nNodes > 0 && v2.nNodes > 0 && d1.n > 0 && d2.n > 0) {
-        hipLaunchKernelGGL(k_tri_match, dim3(v1.nNodes), dim3(64), 0, m->stream, d1, v1, dMp1, dUr1, d2, v2, dMp2, dUr2, P,
+        ORBM_LAUNCH(k_tri_match, dim3(v1.nNodes), dim3(64), 0, m->stream, d1, v1, dMp1, dUr1, d2, v2, dMp2, dUr2, P,
                            dM12, (int*)dBin, (int*)dHist);
         ORBX_HIP_CHECK(hipGetLastError());
     }
     int* dCount = (int*)dHist + HISTO_LENGTH;
-    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, m->stream, d1.n, check_orientation, dM12, (int*)nullptr,
+    ORBM_LAUNCH(k_bow_finish, dim3(1), dim3(256), 0, m->stream, d1.n, check_orientation, dM12, (int*)nullptr,
                        (const int*)dBin, (const int*)dHist, dCount);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
@@ -2963,7 +3008,7 @@ static int run_window_best(orbm_context* m, const DevFrame& kf, int n, const u8*
     P.chi2Gate = chi2Gate;
     if (chi2Gate)
         for (int l = 0; l < nlevels; l++) P.invSigma2[l] = invSigma2[l];
-    hipLaunchKernelGGL(k_window_best, dim3((n + 3) / 4), dim3(256), 0, m->stream, kf, (const int*)cs, (const int*)ci, n, dValid,
+    ORBM_LAUNCH(k_window_best, dim3((n + 3) / 4), dim3(256), 0, m->stream, kf, (const int*)cs, (const int*)ci, n, dValid,
                        dU, dV, dR, dLevel, dDesc, dKfUr, dQUr, P, dIdx, dDist);
     ORBX_HIP_CHECK(hipGetLastError());
     return ORBX_OK;
@@ -3061,7 +3106,7 @@ int orbm_search_by_sim3(orbm_context* m, const orbm_frame* kf1, const orbm_frame
     }
     int* dM12;
     if ((rc = stage_out(m, SL_BW_M12, (int*)match12, (size_t)d1.n, mem_space, &dM12))) return rc;
-    hipLaunchKernelGGL(k_sim3_agree, dim3(1), dim3(256), 0, m->stream, d1.n, d2.n, (const int*)i12, (const int*)dd12,
+    ORBM_LAUNCH(k_sim3_agree, dim3(1), dim3(256), 0, m->stream, d1.n, d2.n, (const int*)i12, (const int*)dd12,
                        (const int*)i21, (const int*)dd21, dM12, (int*)dCount);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)match12, (const int*)dM12, (size_t)d1.n, mem_space))) return rc;
@@ -3107,7 +3152,7 @@ int orbm_distinctive_descriptors(orbm_context* m, const uint8_t* desc, const int
         ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_distinctive, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
         attrSet = true;
     }
-    hipLaunchKernelGGL(k_distinctive, dim3((ngroups + 3) / 4), dim3(256), ldsBytes, m->stream, dDesc, dStart, ngroups, dBest,
+    ORBM_LAUNCH(k_distinctive, dim3((ngroups + 3) / 4), dim3(256), ldsBytes, m->stream, dDesc, dStart, ngroups, dBest,
                        dMed, dOut);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)best, (const int*)dBest, (size_t)ngroups, mem_space))) return rc;
@@ -3137,9 +3182,9 @@ int orbm_filter_by_mask(orbm_context* m, const orbx_keypoint* kps, const uint8_t
     void* dScal;
     if ((rc = pool_get(m, SL_SCALAR, 64, &dScal))) return rc;
     ORBX_HIP_CHECK(hipMemsetAsync(dScal, 0, 64, m->stream));
-    hipLaunchKernelGGL(k_mask_sum, dim3(std::min(h, 1024)), dim3(256), 0, m->stream, dMask, w, h, (i64)stride, (u64*)dScal);
+    ORBM_LAUNCH(k_mask_sum, dim3(std::min(h, 1024)), dim3(256), 0, m->stream, dMask, w, h, (i64)stride, (u64*)dScal);
     ORBX_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_mask_filter, dim3(1), dim3(1024), 0, m->stream, dKps, dDesc, n, dMask, w, h, (i64)stride,
+    ORBM_LAUNCH(k_mask_filter, dim3(1), dim3(1024), 0, m->stream, dKps, dDesc, n, dMask, w, h, (i64)stride,
                        (const u64*)dScal, dOutK, dOutD, (int*)dScal + 4);
     ORBX_HIP_CHECK(hipGetLastError());
     ORBX_HIP_CHECK(hipMemcpyAsync(n_out, (int*)dScal + 4, sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -3168,7 +3213,7 @@ int orbm_pack_keyframe_records(orbm_context* m, const orbx_keypoint* kps, const 
     if ((rc = stage_in(m, SL_F1_DESC, desc, (size_t)n * 32, mem_space, &dDesc))) return rc;
     if ((rc = stage_in(m, SL_RC_IDX, mp_index, (size_t)n, mem_space, &dIdx))) return rc;
     if ((rc = stage_out(m, SL_RC_REC, records, (size_t)n * 64, mem_space, &dRec))) return rc;
-    hipLaunchKernelGGL(k_records, dim3(((size_t)n * 16 + 255) / 256), dim3(256), 0, m->stream, 1, n, (orbx_keypoint*)dKps,
+    ORBM_LAUNCH(k_records, dim3(((size_t)n * 16 + 255) / 256), dim3(256), 0, m->stream, 1, n, (orbx_keypoint*)dKps,
                        (u8*)dDesc, (u64*)dIdx, dRec);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, records, (const u8*)dRec, (size_t)n * 64, mem_space))) return rc;
@@ -3193,7 +3238,7 @@ int orbm_unpack_keyframe_records(orbm_context* m, const uint8_t* records, int n,
     if ((rc = stage_out(m, SL_F1_KPS, kps, (size_t)n, mem_space, &dKps))) return rc;
     if ((rc = stage_out(m, SL_F1_DESC, desc, (size_t)n * 32, mem_space, &dDesc))) return rc;
     if (mp_index && (rc = stage_out(m, SL_RC_IDX, mp_index, (size_t)n, mem_space, &dIdx))) return rc;
-    hipLaunchKernelGGL(k_records, dim3(((size_t)n * 16 + 255) / 256), dim3(256), 0, m->stream, 0, n, dKps, dDesc, (u64*)dIdx,
+    ORBM_LAUNCH(k_records, dim3(((size_t)n * 16 + 255) / 256), dim3(256), 0, m->stream, 0, n, dKps, dDesc, (u64*)dIdx,
                        (u8*)dRec);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, kps, (const orbx_keypoint*)dKps, (size_t)n, mem_space))) return rc;
@@ -3230,7 +3275,7 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
     int c0 = 0;
     do {
         const int rows = std::min(chunkRows, nt - c0);
-        hipLaunchKernelGGL(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq,
+        ORBM_LAUNCH(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq,
                            (const uint4*)(dt + (size_t)c0 * 32), rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0);
         c0 += rows;
     } while (c0 < nt);
@@ -3264,7 +3309,7 @@ int orbm_knn2_merge(orbm_context* m, int nq, int32_t* best_idx_a, int32_t* best_
             return rc;
         ia = (int*)t0; da = (int*)t1; sa = (int*)t2;
     }
-    hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, ia, da, sa, ib, db, sb);
+    ORBM_LAUNCH(k_knn2_merge, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, ia, da, sa, ib, db, sb);
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)best_idx_a, (const int*)ia, (size_t)nq, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)best_d_a, (const int*)da, (size_t)nq, mem_space))) return rc;
