@@ -665,8 +665,9 @@ __global__ __launch_bounds__(256) void k_projq_candidates(DevFrame train, const 
                                                            const int* __restrict__ cellItems,
                                                            const float* __restrict__ trainURight, ProjQueries q, int mode,
                                                            const int* __restrict__ offs, int* candIdx, int* candDist,
-                                                           int* counts) {
-    projq_candidates_body(train, cellStart, cellItems, trainURight, q, mode, offs, candIdx, candDist, counts);
+                                                           int* counts, u32* slab, int slabCap, int* overflow) {
+    projq_candidates_body(train, cellStart, cellItems, trainURight, q, mode, offs, candIdx, candDist, counts, slab, slabCap,
+                          overflow);
 }
 __global__ __launch_bounds__(256) void k_projq_candidates_jobs(const ProjJob* __restrict__ jobs, int mode) {
     const ProjJob& J = jobs[blockIdx.y];
@@ -909,9 +910,11 @@ template <bool RATIO>
 __global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQueries q, ProjPolicy pol,
                                                             const int* __restrict__ offs, const int* __restrict__ candIdx,
                                                             const int* __restrict__ candDist, int* claimed, u8* claimedObs,
-                                                            int* qBest, int* qBin, int* nmatchesOut, int total) {
+                                                            int* qBest, int* qBin, int* nmatchesOut, int total,
+                                                            const u32* __restrict__ slab, int slabCap) {
     extern __shared__ __align__(16) u8 rsm[];
-    projq_resolve_lds_body<RATIO>(rsm, train, q, pol, offs, candIdx, candDist, claimed, claimedObs, qBest, qBin, nmatchesOut, total);
+    projq_resolve_lds_body<RATIO>(rsm, train, q, pol, offs, candIdx, candDist, claimed, claimedObs, qBest, qBin, nmatchesOut, total,
+                                  slab, slabCap);
 }
 // One job (frame pair) per workgroup; the dynamic LDS is sized by the host for the largest job.
 template <bool RATIO>
@@ -2451,37 +2454,45 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
         }
         return ORBX_OK;
     }
+    // claim state first, so that it travels with the other staged inputs
+    const int* dClaimIn;
+    const u8* dClaimObsIn;
+    if ((rc = stage_in(m, SL_STATE_A, (const int*)claimed, (size_t)nt, mem_space, &dClaimIn)) ||
+        (rc = stage_in(m, SL_STATE_B, (const u8*)claimed_obs, (size_t)nt, mem_space, &dClaimObsIn)))
+        return rc;
+    int* dClaim = const_cast<int*>(dClaimIn);
+    u8* dClaimObs = const_cast<u8*>(dClaimObsIn);
     int *cs, *ci;
     if ((rc = build_grid(m, train, &cs, &ci))) return rc;
-    void *cnt, *offs, *qn, *scal;
+    void *cnt, *offs, *qn, *scal, *slab;
+    // One walk per query when no query has more than SLAB_CAP candidates: they land, distance included, in a
+    // fixed slot per query, and the claim resolution packs them into LDS.  Otherwise a second walk fills a CSR.
+    const int SLAB_CAP = 32;
     if ((rc = pool_get(m, SL_COUNTS, (size_t)nq * 4, &cnt)) || (rc = pool_get(m, SL_OFFS, (size_t)(nq + 1) * 4, &offs)) ||
-        (rc = pool_get(m, SL_STATE_D, (size_t)nq * 4, &qn)) || (rc = pool_get(m, SL_SCALAR, 64, &scal)))
+        (rc = pool_get(m, SL_STATE_D, (size_t)nq * 4, &qn)) || (rc = pool_get(m, SL_SCALAR, 64, &scal)) ||
+        (rc = pool_get(m, SL_JB_SLAB, (size_t)nq * SLAB_CAP * 4, &slab)))
         return rc;
+    int* dOverflow = (int*)scal + 8;
+    ORBX_HIP_CHECK(hipMemsetAsync(dOverflow, 0, sizeof(int), m->stream));
     ORBM_LAUNCH(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
-                       dTrainURight, q, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt);
+                dTrainURight, q, 3, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt, (u32*)slab, SLAB_CAP, dOverflow);
     ORBM_LAUNCH(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, nq);
-    int total = 0;
-    if ((rc = d2h(m, &total, (int*)offs + nq, sizeof(int)))) return rc;
+    int total = 0, overflow = 0;
+    if ((rc = d2h(m, &total, (int*)offs + nq, sizeof(int))) || (rc = d2h(m, &overflow, dOverflow, sizeof(int)))) return rc;
     ORBX_HIP_CHECK(sync_deliver(m));
-    void *cIdx, *cDist;
-    if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
-        (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
-        return rc;
-    ORBM_LAUNCH(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
-                       dTrainURight, q, 2, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr);
-    int* dClaim;
-    u8* dClaimObs;
-    int* dQBest;
-    if (mem_space == ORBX_MEM_DEVICE) {
-        dClaim = (int*)claimed;
-        dClaimObs = claimed_obs;
-    } else {
-        void *p1, *p2;
-        if ((rc = pool_get(m, SL_STATE_A, (size_t)nt * 4, &p1)) || (rc = pool_get(m, SL_STATE_B, (size_t)nt, &p2))) return rc;
-        dClaim = (int*)p1;
-        dClaimObs = (u8*)p2;
-        if ((rc = h2d(m, dClaim, claimed, (size_t)nt * 4)) || (rc = h2d(m, dClaimObs, claimed_obs, (size_t)nt))) return rc;
+    // the whole problem in LDS when it fits (any ordinary frame pair does): see k_projq_resolve_lds
+    const size_t ldsBytes = (size_t)total * 4 + ((size_t)nq + 1) * 4 + (size_t)nt * (8 + (pol.ratioTest ? 4 : 0) + 2) + (size_t)nq + 16;
+    const bool fits = ldsBytes <= 150 * 1024 && total < 65536 && nt <= 65536;
+    const bool oneWalk = fits && !overflow;
+    void *cIdx = nullptr, *cDist = nullptr;
+    if (!oneWalk) {
+        if ((rc = pool_get(m, SL_CAND_IDX, (size_t)std::max(total, 1) * 4, &cIdx)) ||
+            (rc = pool_get(m, SL_CAND_DIST, (size_t)std::max(total, 1) * 4, &cDist)))
+            return rc;
+        ORBM_LAUNCH(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
+                    dTrainURight, q, 2, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr, (u32*)nullptr, 0, (int*)nullptr);
     }
+    int* dQBest;
     if (mem_space == ORBX_MEM_DEVICE && query_best) {
         dQBest = (int*)query_best;
     } else {
@@ -2489,9 +2500,7 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
         if ((rc = pool_get(m, SL_STATE_C, (size_t)nq * 4, &p3))) return rc;
         dQBest = (int*)p3;
     }
-    // the whole problem in LDS when it fits (any ordinary frame pair does): see k_projq_resolve_lds
-    const size_t ldsBytes = (size_t)total * 4 + ((size_t)nq + 1) * 4 + (size_t)nt * (8 + (pol.ratioTest ? 4 : 0) + 2) + (size_t)nq + 16;
-    if (ldsBytes <= 150 * 1024 && total < 65536 && nt <= 65536) {
+    if (fits) {
         if (!m->resolveLdsReady) {
             ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds<false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -2501,7 +2510,8 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
         }
         auto kr = pol.ratioTest ? k_projq_resolve_lds<true> : k_projq_resolve_lds<false>;
         ORBM_LAUNCH(kr, dim3(1), dim3(256), ldsBytes, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
-                           (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal, total);
+                    (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal, total,
+                    (const u32*)(oneWalk ? slab : nullptr), oneWalk ? SLAB_CAP : 0);
     } else {
         ORBM_LAUNCH(k_projq_resolve, dim3(1), dim3(64), 0, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
                            (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal);
@@ -2850,6 +2860,15 @@ int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const o
     return ORBX_OK;
 }
 
+// Start state of the vocabulary-guided searches in one launch: match tables and bins at -1, histogram at 0.
+__global__ void k_bow_init(int* a, int na, int* b, int nb, int* c, int nc, int* zero, int nz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a && i < na) a[i] = -1;
+    if (b && i < nb) b[i] = -1;
+    if (c && i < nc) c[i] = -1;
+    if (i < nz) zero[i] = 0;
+}
+
 static int make_featvec(orbm_context* m, const orbm_feature_vector* fv, int slotNodes, int slotStart, int slotItems,
                         int memSpace, DevFeatVec* out) {
     if (!fv || fv->n_nodes < 0 || fv->n_items < 0 || (fv->n_nodes > 0 && (!fv->node_ids || !fv->start)) ||
@@ -2913,10 +2932,11 @@ int orbm_search_by_bow(orbm_context* m, const orbm_frame* f1, const orbm_feature
     if ((rc = stage_out(m, SL_BW_M21, (int*)match21, (size_t)d2.n, mem_space, &dM21))) return rc;
     if ((rc = pool_get(m, SL_BW_BIN, (size_t)std::max(d1.n, 1) * sizeof(int), &dBin))) return rc;
     if ((rc = pool_get(m, SL_BW_HIST, (HISTO_LENGTH + 2) * sizeof(int), &dHist))) return rc;
-    if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dM12, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
-    if (d2.n) ORBX_HIP_CHECK(hipMemsetAsync(dM21, 0xFF, (size_t)d2.n * sizeof(int), m->stream));
-    if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dBin, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
-    ORBX_HIP_CHECK(hipMemsetAsync(dHist, 0, (HISTO_LENGTH + 2) * sizeof(int), m->stream));
+    {
+        const int most = std::max(std::max(d1.n, d2.n), HISTO_LENGTH + 2);
+        ORBM_LAUNCH(k_bow_init, dim3((most + 255) / 256), dim3(256), 0, m->stream, dM12, d1.n, dM21, d2.n, (int*)dBin, d1.n,
+                    (int*)dHist, HISTO_LENGTH + 2);
+    }
     if (v1.nNodes > 0 && v2.nNodes > 0 && d1.n > 0 && d2.n > 0) {
         ORBM_LAUNCH(k_bow_match, dim3(v1.nNodes), dim3(64), 0, m->stream, d1, v1, dValid1, d2, v2, dValid2, max_dist,
                            nn_ratio, check_orientation, dM12, dM21, (int*)dBin, (int*)dHist);
@@ -2977,9 +2997,11 @@ int orbm_search_for_triangulation(orbm_context* m, const orbm_frame* f1, const o
     if ((rc = stage_out(m, SL_BW_M12, (int*)match12, (size_t)d1.n, mem_space, &dM12))) return rc;
     if ((rc = pool_get(m, SL_BW_BIN, (size_t)std::max(d1.n, 1) * sizeof(int), &dBin))) return rc;
     if ((rc = pool_get(m, SL_BW_HIST, (HISTO_LENGTH + 2) * sizeof(int), &dHist))) return rc;
-    if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dM12, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
-    if (d1.n) ORBX_HIP_CHECK(hipMemsetAsync(dBin, 0xFF, (size_t)d1.n * sizeof(int), m->stream));
-    ORBX_HIP_CHECK(hipMemsetAsync(dHist, 0, (HISTO_LENGTH + 2) * sizeof(int), m->stream));
+    {
+        const int most = std::max(d1.n, HISTO_LENGTH + 2);
+        ORBM_LAUNCH(k_bow_init, dim3((most + 255) / 256), dim3(256), 0, m->stream, dM12, d1.n, (int*)nullptr, 0, (int*)dBin, d1.n,
+                    (int*)dHist, HISTO_LENGTH + 2);
+    }
     if (v1.nNodes > 0 && v2.nNodes > 0 && d1.n > 0 && d2.n > 0) {
         ORBM_LAUNCH(k_tri_match, dim3(v1.nNodes), dim3(64), 0, m->stream, d1, v1, dMp1, dUr1, d2, v2, dMp2, dUr2, P,
                            dM12, (int*)dBin, (int*)dHist);
