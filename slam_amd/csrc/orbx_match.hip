@@ -1879,9 +1879,20 @@ __global__ __launch_bounds__(1024) void k_stereo_median(int n, const int* __rest
 // best = min(best, key): unique keys make "first row wins ties" and "second counts duplicates
 // of the minimum" fall out of the ordering.
 __global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt,
-                                               int indexBase, int* bestIdx, int* bestD, int* secondD, int mergeWithOutput) {
+                                               int indexBase, int* bestIdx, int* bestD, int* secondD, int mergeWithOutput,
+                                               int sliceRows) {
     const int tid = threadIdx.x;
     const int q0 = (blockIdx.x * 256 + tid) * KNN_QPT;
+    if (sliceRows > 0) {
+        // few queries: blockIdx.y takes a slice of the train rows and writes its own partial results
+        const int r0 = (int)blockIdx.y * sliceRows;
+        t += (i64)r0 * 2;
+        nt = min(sliceRows, nt - r0);
+        indexBase += r0;
+        bestIdx += (i64)blockIdx.y * nq;
+        bestD += (i64)blockIdx.y * nq;
+        secondD += (i64)blockIdx.y * nq;
+    }
     uint4 qa[KNN_QPT][2];
     u32 best[KNN_QPT], second[KNN_QPT];
 #pragma unroll
@@ -1997,6 +2008,24 @@ __global__ void k_knn2_merge(int nq, int* ia, int* da, int* sa, const int* ib, c
         ia[i] = ib[i];
     }
     sa[i] = s;
+}
+
+// The partials of consecutive train slices (slice-major arrays of nq entries) folded in slice order by the same rule.
+__global__ void k_knn2_merge_slices(int nq, int nSlices, const int* pi, const int* pd, const int* ps, int* oi, int* od, int* os) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int bi = pi[i], bd = pd[i], sd = ps[i];
+    for (int s = 1; s < nSlices; s++) {
+        const int ib = pi[(i64)s * nq + i], db = pd[(i64)s * nq + i], sb = ps[(i64)s * nq + i];
+        sd = min(max(bd, db), min(sd, sb));
+        if (db < bd) {
+            bd = db;
+            bi = ib;
+        }
+    }
+    oi[i] = bi;
+    od[i] = bd;
+    os[i] = sd;
 }
 
 }  // namespace
@@ -3294,13 +3323,29 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
     if ((rc = stage_out(m, SL_KNN_S, (int*)second_d, (size_t)nq, mem_space, &ds))) return rc;
     const int blocks = (nq + 256 * KNN_QPT - 1) / (256 * KNN_QPT);
     const int chunkRows = 1 << KNN_IDX_BITS;
-    int c0 = 0;
-    do {
-        const int rows = std::min(chunkRows, nt - c0);
-        ORBM_LAUNCH(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq,
-                           (const uint4*)(dt + (size_t)c0 * 32), rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0);
-        c0 += rows;
-    } while (c0 < nt);
+    if (blocks < 128 && nt >= 128 && nt <= chunkRows) {
+        // too few queries to fill the GPU: the train rows are split over blockIdx.y and the partials folded in order
+        int slices = std::min(nt / 32, std::max(1024 / blocks, 1));
+        const int sliceRows = ((nt + slices - 1) / slices + 7) & ~7;
+        slices = (nt + sliceRows - 1) / sliceRows;
+        void *pi, *pd, *ps;
+        const size_t partBytes = (size_t)slices * nq * sizeof(int);
+        if ((rc = pool_get(m, SL_KNN_I2, partBytes, &pi)) || (rc = pool_get(m, SL_KNN_D2, partBytes, &pd)) ||
+            (rc = pool_get(m, SL_KNN_S2, partBytes, &ps)))
+            return rc;
+        ORBM_LAUNCH(k_knn2, dim3(blocks, slices), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt, nt,
+                    train_index_base, (int*)pi, (int*)pd, (int*)ps, 0, sliceRows);
+        ORBM_LAUNCH(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, slices, (const int*)pi,
+                    (const int*)pd, (const int*)ps, di, dd, ds);
+    } else {
+        int c0 = 0;
+        do {
+            const int rows = std::min(chunkRows, nt - c0);
+            ORBM_LAUNCH(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)(dt + (size_t)c0 * 32),
+                        rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0, 0);
+            c0 += rows;
+        } while (c0 < nt);
+    }
     ORBX_HIP_CHECK(hipGetLastError());
     if ((rc = copy_back(m, (int*)best_idx, (const int*)di, (size_t)nq, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)best_d, (const int*)dd, (size_t)nq, mem_space))) return rc;

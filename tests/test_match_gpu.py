@@ -190,7 +190,7 @@ def test_empty_frames(matcher, frames):
     assert n == 0 and (m12 == -1).all()
 
 
-@pytest.mark.parametrize("nq,nt", [(1, 1), (513, 1000), (2048, 4099), (300, 70000)])
+@pytest.mark.parametrize("nq,nt", [(1, 1), (7, 131), (513, 1000), (1000, 127), (2048, 4099), (300, 70000), (140000, 300)])
 def test_knn2_small(oracle, matcher, nq, nt):
     q = synth.synth_descriptors(nq, 100 + nq)
     t = synth.synth_descriptors(nt, 200 + nt)
