@@ -98,26 +98,47 @@ __device__ __forceinline__ void grid_build_body(DevFrame f, int* cellStart, int*
         cellStart[GRID_CELLS] = run;
     }
     __syncthreads();
-    // Items of a cell keep ascending keypoint order: one wave walks the keypoints 64 at a time, ranks a
-    // keypoint among the lower lanes that fall in the same cell and advances the cell's write cursor
-    // (hist[] holds it) by the number the chunk put there.  Linear in the number of keypoints.
-    if (tid < 64) {
-        for (int base = 0; base < f.n; base += 64) {
-            const int i = base + lane;
-            const int c = i < f.n ? (int)cellOf[i] : 0xFFFF;
+    // Items of a cell keep ascending keypoint order.  In chunks of 64 keypoints a keypoint is ranked among
+    // the lower lanes that fall in the same cell (all 16 waves, a chunk each); then one wave walks the
+    // chunks in order and advances each cell's write cursor (hist[] holds it) by the number the chunk
+    // put there.  Linear in the number of keypoints; 8192 keypoints per round of the two steps.
+    __shared__ u16 sCell[8192];
+    __shared__ u16 sRank[8192];  // rank in the chunk | (count in the chunk << 8)
+    for (int sb = 0; sb < f.n; sb += 8192) {
+        const int m = min(8192, f.n - sb);
+        for (int cb = wv * 64; cb < m; cb += 1024) {
+            const int k = cb + lane;
+            const int c = k < m ? (int)cellOf[sb + k] : 0xFFFF;
             int r = 0, cnt = 0;
+#pragma unroll 8
             for (int l = 0; l < 64; l++) {
                 const int cl = __builtin_amdgcn_readlane(c, l);
                 const bool same = cl == c;
                 r += (same && l < lane) ? 1 : 0;
                 cnt += same ? 1 : 0;
             }
-            if (c != 0xFFFF) {
-                const int start = hist[c];
-                cellItems[start + r] = i;
-                if (r == cnt - 1) hist[c] = start + cnt;  // the last of the cell in this chunk moves the cursor
+            if (k < m) {
+                sCell[k] = (u16)c;
+                sRank[k] = (u16)(r | (cnt << 8));
             }
         }
+        __syncthreads();
+        if (tid < 64) {
+            for (int cb = 0; cb < m; cb += 64) {
+                const int k = cb + lane;
+                if (k < m) {
+                    const int c = sCell[k];
+                    const int rc = sRank[k];
+                    const int r = rc & 0xFF, cnt = rc >> 8;
+                    if (c != 0xFFFF) {
+                        const int start = hist[c];
+                        cellItems[start + r] = sb + k;
+                        if (r == cnt - 1) hist[c] = start + cnt;  // the last of the cell in this chunk moves the cursor
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
