@@ -1288,6 +1288,81 @@ __global__ __launch_bounds__(64) void k_bow_match(DevFrame f1, DevFeatVec v1, co
     const int n2 = find_node(v2, v1.nodeIds[n1]);
     if (n2 < 0) return;
     const int b2 = v2.start[n2], e2 = v2.start[n2 + 1];
+    {
+        // A node of ordinary size (at most BOW_CAP pairs): all distances of the node first, in parallel,
+        // into LDS; the serial claims of the reference then run from LDS alone, and the matches are
+        // written (and their rotation bins counted) in parallel at the end.
+        constexpr int BOW_CAP = 4096;
+        __shared__ u16 sD[BOW_CAP];      // distance of pair (a, k), 0xFFFF when either side is not eligible
+        __shared__ u16 sIdx1[BOW_CAP], sIdx2[BOW_CAP], sMatch[BOW_CAP];
+        __shared__ u8 sTaken[BOW_CAP];
+        const int b1 = v1.start[n1], n1c = v1.start[n1 + 1] - b1, n2c = e2 - b2;
+        if (n1c <= 0 || n2c <= 0) return;
+        if ((i64)n1c * n2c <= BOW_CAP && f1.n <= 65535 && f2.n <= 65535) {
+            for (int k = lane; k < n2c; k += 64) {
+                sTaken[k] = 0;
+                sIdx2[k] = (u16)v2.items[b2 + k];
+            }
+            for (int a = lane; a < n1c; a += 64) {
+                sIdx1[a] = (u16)v1.items[b1 + a];
+                sMatch[a] = 0xFFFF;
+            }
+            __syncthreads();
+            const int pairs = n1c * n2c;
+            for (int p = lane; p < pairs; p += 64) {
+                const int a = p / n2c, k = p - a * n2c;
+                const int idx1 = sIdx1[a], idx2 = sIdx2[k];
+                u32 dist = 0xFFFFu;
+                if (valid1[idx1] && (!valid2 || valid2[idx2])) {
+                    const uint4* d1 = (const uint4*)(f1.desc + (i64)idx1 * 32);
+                    const uint4* d2 = (const uint4*)(f2.desc + (i64)idx2 * 32);
+                    dist = (u32)hamming256(d1[0], d1[1], d2[0], d2[1]);
+                }
+                sD[p] = (u16)dist;
+            }
+            __syncthreads();
+            for (int a = 0; a < n1c; a++) {
+                u32 bkey = 0xFFFFFFFFu, second = 256;
+                for (int k = lane; k < n2c; k += 64) {
+                    const u32 dist = sD[a * n2c + k];
+                    if (sTaken[k] || dist == 0xFFFFu) continue;
+                    const u32 key = (dist << 16) | (u32)k;
+                    if (key < bkey) {
+                        if (bkey != 0xFFFFFFFFu) second = min(second, bkey >> 16);
+                        bkey = key;
+                    } else {
+                        second = min(second, dist);
+                    }
+                }
+                const u32 win = wave_min_u32_dpp(bkey);
+                const u32 mine = bkey == win ? second : (bkey == 0xFFFFFFFFu ? 256u : (bkey >> 16));
+                const u32 bestDist2 = wave_min_u32_dpp(mine);
+                if (win == 0xFFFFFFFFu) continue;
+                const int bestDist1 = (int)(win >> 16);
+                if (bestDist1 <= maxDist && (float)bestDist1 < __fmul_rn(nnRatio, (float)bestDist2)) {
+                    const int bestK = (int)(win & 0xFFFFu);
+                    const u16 taken2 = sIdx2[bestK];
+                    for (int k = lane; k < n2c; k += 64)
+                        if (sIdx2[k] == taken2) sTaken[k] = 1;
+                    if (lane == 0) sMatch[a] = (u16)bestK;
+                }
+            }
+            __syncthreads();
+            for (int a = lane; a < n1c; a += 64) {
+                const int mk = sMatch[a];
+                if (mk == 0xFFFF) continue;
+                const int idx1 = sIdx1[a], idx2 = sIdx2[mk];
+                match12[idx1] = idx2;
+                match21[idx2] = idx1;
+                if (checkOri) {
+                    const int bin = rot_bin(f1.kps[idx1].angle, f2.kps[idx2].angle);
+                    bin12[idx1] = bin;
+                    atomicAdd(&hist[bin], 1);
+                }
+            }
+            return;
+        }
+    }
     for (int a = v1.start[n1]; a < v1.start[n1 + 1]; a++) {
         const int idx1 = (int)v1.items[a];
         if (!valid1[idx1]) continue;
