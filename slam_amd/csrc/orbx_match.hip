@@ -937,6 +937,25 @@ __global__ __launch_bounds__(256) void k_projq_resolve_lds(DevFrame train, ProjQ
     projq_resolve_lds_body<RATIO>(rsm, train, q, pol, offs, candIdx, candDist, claimed, claimedObs, qBest, qBin, nmatchesOut, total,
                                   slab, slabCap);
 }
+// The same launched before the host knows the candidate total: the kernel reads it, and declines (flag
+// set, nothing else written) when a query overflowed its slot or the problem does not fit the LDS it
+// was given; the host then takes the two-walk route.  Saves the host round trip in the middle of a call.
+template <bool RATIO>
+__global__ __launch_bounds__(256) void k_projq_resolve_lds_auto(DevFrame train, ProjQueries q, ProjPolicy pol,
+                                                                 const int* __restrict__ offs, int* claimed, u8* claimedObs,
+                                                                 int* qBest, int* qBin, int* nmatchesOut,
+                                                                 const u32* __restrict__ slab, int slabCap,
+                                                                 const int* __restrict__ overflow, int fixedBytes, int ldsBytes,
+                                                                 int* declined) {
+    extern __shared__ __align__(16) u8 rsm[];
+    const int total = offs[q.n];
+    if (*overflow || total >= 65536 || (i64)total * 4 + fixedBytes > (i64)ldsBytes) {
+        if (threadIdx.x == 0) *declined = 1;
+        return;
+    }
+    projq_resolve_lds_body<RATIO>(rsm, train, q, pol, offs, nullptr, nullptr, claimed, claimedObs, qBest, qBin, nmatchesOut, total,
+                                  slab, slabCap);
+}
 // One job (frame pair) per workgroup; the dynamic LDS is sized by the host for the largest job.
 template <bool RATIO>
 __global__ __launch_bounds__(256) void k_projq_resolve_lds_jobs(const ProjJob* __restrict__ jobs, ProjPolicy pol, int useSlab) {
@@ -2597,11 +2616,48 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
         (rc = pool_get(m, SL_STATE_D, (size_t)nq * 4, &qn)) || (rc = pool_get(m, SL_SCALAR, 64, &scal)) ||
         (rc = pool_get(m, SL_JB_SLAB, (size_t)nq * SLAB_CAP * 4, &slab)))
         return rc;
-    int* dOverflow = (int*)scal + 8;
-    ORBX_HIP_CHECK(hipMemsetAsync(dOverflow, 0, sizeof(int), m->stream));
+    int* dOverflow = (int*)scal + 8;   // followed by the "declined" flag of the resolution
+    ORBX_HIP_CHECK(hipMemsetAsync(dOverflow, 0, 2 * sizeof(int), m->stream));
     ORBM_LAUNCH(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
                 dTrainURight, q, 3, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)cnt, (u32*)slab, SLAB_CAP, dOverflow);
     ORBM_LAUNCH(k_scan, dim3(1), dim3(1024), 0, m->stream, (const int*)cnt, (int*)offs, nq);
+    int* dQBest;
+    if (mem_space == ORBX_MEM_DEVICE && query_best) {
+        dQBest = (int*)query_best;
+    } else {
+        void* p3;
+        if ((rc = pool_get(m, SL_STATE_C, (size_t)nq * 4, &p3))) return rc;
+        dQBest = (int*)p3;
+    }
+    if (!m->resolveLdsReady) {
+        ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024));
+        ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024));
+        ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds_auto<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds_auto<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        m->resolveLdsReady = true;
+    }
+    // The resolution is launched at once, on the full LDS allowance (a single workgroup runs, so the
+    // size costs nothing); it declines when the problem is too large for that, which the host learns with the results.
+    const size_t fixedBytes = ((size_t)nq + 1) * 4 + (size_t)nt * (8 + (pol.ratioTest ? 4 : 0) + 2) + (size_t)nq + 16;
+    if (nt <= 65536 && fixedBytes + (size_t)nq * 4 <= 150 * 1024) {
+        int* dDeclined = dOverflow + 1;
+        auto ka = pol.ratioTest ? k_projq_resolve_lds_auto<true> : k_projq_resolve_lds_auto<false>;
+        ORBM_LAUNCH(ka, dim3(1), dim3(256), 150 * 1024, m->stream, train, q, pol, (const int*)offs, dClaim, dClaimObs, dQBest,
+                    (int*)qn, (int*)scal, (const u32*)slab, SLAB_CAP, (const int*)dOverflow, (int)fixedBytes, 150 * 1024, dDeclined);
+        ORBX_HIP_CHECK(hipGetLastError());
+        int declined = 0;
+        if ((rc = copy_back(m, (int*)claimed, (const int*)dClaim, (size_t)nt, mem_space))) return rc;
+        if ((rc = copy_back(m, claimed_obs, (const u8*)dClaimObs, (size_t)nt, mem_space))) return rc;
+        if (query_best && (rc = copy_back(m, (int*)query_best, (const int*)dQBest, (size_t)nq, mem_space))) return rc;
+        if ((rc = d2h(m, nmatches, scal, sizeof(int))) || (rc = d2h(m, &declined, dDeclined, sizeof(int)))) return rc;
+        ORBX_HIP_CHECK(sync_deliver(m));
+        if (!declined) return ORBX_OK;
+        *nmatches = 0;
+    }
     int total = 0, overflow = 0;
     if ((rc = d2h(m, &total, (int*)offs + nq, sizeof(int))) || (rc = d2h(m, &overflow, dOverflow, sizeof(int)))) return rc;
     ORBX_HIP_CHECK(sync_deliver(m));
@@ -2617,22 +2673,7 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
         ORBM_LAUNCH(k_projq_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->stream, train, (const int*)cs, (const int*)ci,
                     dTrainURight, q, 2, (const int*)offs, (int*)cIdx, (int*)cDist, (int*)nullptr, (u32*)nullptr, 0, (int*)nullptr);
     }
-    int* dQBest;
-    if (mem_space == ORBX_MEM_DEVICE && query_best) {
-        dQBest = (int*)query_best;
-    } else {
-        void* p3;
-        if ((rc = pool_get(m, SL_STATE_C, (size_t)nq * 4, &p3))) return rc;
-        dQBest = (int*)p3;
-    }
     if (fits) {
-        if (!m->resolveLdsReady) {
-            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds<false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds<true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            m->resolveLdsReady = true;
-        }
         auto kr = pol.ratioTest ? k_projq_resolve_lds<true> : k_projq_resolve_lds<false>;
         ORBM_LAUNCH(kr, dim3(1), dim3(256), ldsBytes, m->stream, train, q, pol, (const int*)offs, (const int*)cIdx,
                     (const int*)cDist, dClaim, dClaimObs, dQBest, (int*)qn, (int*)scal, total,
