@@ -2165,6 +2165,8 @@ struct orbm_context {
     unsigned char* dArena = nullptr;
     std::vector<void*> dArenaRetired;
     size_t upLo = 0, upHi = 0;          // staged and not uploaded yet: [upLo, upHi) of the current arena
+    // Result arrays live in the mirror too: the pieces asked back are fetched at the next wait, neighbours in one copy.
+    std::vector<std::pair<size_t, size_t>> downloads;  // (offset, bytes) in the current arena
     hipError_t asyncError = hipSuccess;  // first failure of a deferred upload, reported by the next wait
     struct Delivery {
         void* dst;
@@ -2178,6 +2180,7 @@ namespace {
 
 hipError_t sync_deliver(orbm_context* m);
 void flush_uploads(orbm_context* m);
+void flush_downloads(orbm_context* m);
 // every kernel launch of the host side goes through this: staged inputs are uploaded first
 #define ORBM_LAUNCH(...)                 \
     do {                                 \
@@ -2219,6 +2222,7 @@ void* arena_alloc(orbm_context* m, size_t bytes) {
     if (m->arenaUsed + need > m->arenaCap) {
         // blocks handed out earlier in this call stay valid: the old arena is kept until the next call
         const size_t cap = std::max(m->arenaCap * 2, std::max(need * 2, (size_t)1 << 20));
+        flush_downloads(m);
         flush_uploads(m);  // what is staged so far belongs to the old pair of buffers
         void *p = nullptr, *dp = nullptr;
         if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
@@ -2248,11 +2252,35 @@ void* arena_alloc(orbm_context* m, size_t bytes) {
 void arena_reset(orbm_context* m) {
     m->arenaUsed = 0;
     m->upLo = m->upHi = 0;
+    m->downloads.clear();
     for (void* p : m->arenaRetired) (void)hipHostFree(p);
     m->arenaRetired.clear();
     for (void* p : m->dArenaRetired) (void)hipFree(p);
     m->dArenaRetired.clear();
     m->pending.clear();
+}
+
+// Issues the device-to-host copies of the result pieces recorded so far; pieces that touch go as one copy.
+void flush_downloads(orbm_context* m) {
+    if (m->downloads.empty()) return;
+    std::sort(m->downloads.begin(), m->downloads.end());
+    size_t lo = m->downloads[0].first, hi = lo + m->downloads[0].second;
+    auto issue = [&]() {
+        const hipError_t e = hipMemcpyAsync(m->arena + lo, m->dArena + lo, hi - lo, hipMemcpyDeviceToHost, m->stream);
+        if (e != hipSuccess && m->asyncError == hipSuccess) m->asyncError = e;
+    };
+    for (size_t k = 1; k < m->downloads.size(); k++) {
+        const size_t o = m->downloads[k].first, b = m->downloads[k].second;
+        if (o <= hi) {
+            hi = std::max(hi, o + b);
+        } else {
+            issue();
+            lo = o;
+            hi = o + b;
+        }
+    }
+    issue();
+    m->downloads.clear();
 }
 
 void flush_uploads(orbm_context* m) {
@@ -2282,6 +2310,7 @@ int d2h(orbm_context* m, void* host, const void* dev, size_t bytes) {
 
 hipError_t sync_deliver(orbm_context* m) {
     flush_uploads(m);
+    flush_downloads(m);
     const hipError_t e = hipStreamSynchronize(m->stream);
     if (e != hipSuccess) return e;
     if (m->asyncError != hipSuccess) {
@@ -2318,17 +2347,26 @@ int stage_out(orbm_context* m, int slot, T* dst, size_t count, int memSpace, T**
         *out = dst;
         return ORBX_OK;
     }
-    void* d = nullptr;
-    int rc = pool_get(m, slot, std::max(count, (size_t)1) * sizeof(T), &d);
-    if (rc) return rc;
-    *out = (T*)d;
+    (void)slot;
+    unsigned char* p = (unsigned char*)arena_alloc(m, std::max(count * sizeof(T), (size_t)64));
+    if (!p) return ORBX_ERR_HIP;
+    *out = (T*)(m->dArena + (size_t)(p - m->arena));
     return ORBX_OK;
 }
 
 template <typename T>
 int copy_back(orbm_context* m, T* host, const T* dev, size_t count, int memSpace) {
     if (memSpace == ORBX_MEM_DEVICE || count == 0) return ORBX_OK;
-    return d2h(m, host, dev, count * sizeof(T));
+    const unsigned char* d = (const unsigned char*)dev;
+    const size_t bytes = count * sizeof(T);
+    if (m->dArena && d >= m->dArena && d + bytes <= m->dArena + m->arenaCap) {
+        // a block of the mirror: it lands at the same offset of the pinned arena, fetched at the next wait
+        const size_t off = (size_t)(d - m->dArena);
+        m->downloads.push_back(std::make_pair(off, std::min((bytes + 63) & ~(size_t)63, m->arenaCap - off)));  // padded: neighbours touch
+        m->pending.push_back({host, m->arena + off, bytes});
+        return ORBX_OK;
+    }
+    return d2h(m, host, dev, bytes);
 }
 
 int make_frame(orbm_context* m, const orbm_frame* f, int slotKps, int slotDesc, int memSpace, DevFrame* out) {
