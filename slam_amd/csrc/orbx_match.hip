@@ -217,23 +217,23 @@ __device__ __forceinline__ int walk_window(const DevFrame& f, const int* __restr
     return count;
 }
 
-// The same walk with 16 lanes per query, four queries to a wave, for windows of a few cells (a
+// The same walk with G (16 or 8) lanes per query, four or eight queries to a wave, for windows of a few cells (a
 // frame-to-frame search at th 7..15 sees a dozen keypoints in its cell rectangle: one query per wave
 // leaves 60 lanes idle behind four dependent loads per grid column).  The columns' CSR runs are
-// concatenated (prefix sum over the columns, 16 at a time), so one trip takes 16 items across all
+// concatenated (prefix sum over the columns, G at a time), so one trip takes G items across all
 // columns in window order.  All 64 lanes stay in the loops (the shuffles and ballots need them);
 // `active` masks a group without a query.
-template <typename Emit>
-__device__ __forceinline__ int walk_window_g16(const DevFrame& f, const int* __restrict__ cellStart,
+template <int G, typename Emit>
+__device__ __forceinline__ int walk_window_sub(const DevFrame& f, const int* __restrict__ cellStart,
                                                const int* __restrict__ cellItems, const float* __restrict__ uRight,
                                                const Query& q, bool active, Emit emit) {
-    const int lane = threadIdx.x & 63, sub = lane & 15, shift = lane & 48;
+    const int lane = threadIdx.x & 63, sub = lane & (G - 1), shift = lane & (64 - G);
     Window w = window_cells(f, q.x, q.y, q.r);
     const bool live = active && !w.empty;
     const int ncols = live ? w.x1 - w.x0 + 1 : 0;
     const bool checkLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
     int count = 0;
-    for (int c0 = 0; __any(c0 < ncols); c0 += 16) {
+    for (int c0 = 0; __any(c0 < ncols); c0 += G) {
         const int c = c0 + sub;
         int b = 0, len = 0;
         if (c < ncols) {
@@ -242,22 +242,22 @@ __device__ __forceinline__ int walk_window_g16(const DevFrame& f, const int* __r
         }
         int incl = len;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-            const int t = __shfl_up(incl, o, 16);
+        for (int o = 1; o < G; o <<= 1) {
+            const int t = __shfl_up(incl, o, G);
             if (sub >= o) incl += t;
         }
-        const int total = __shfl(incl, 15, 16);
-        for (int t0 = 0; __any(t0 < total); t0 += 16) {
+        const int total = __shfl(incl, G - 1, G);
+        for (int t0 = 0; __any(t0 < total); t0 += G) {
             const int t = t0 + sub;
             // column of item t = number of columns whose run ends at or before t
             int col = 0;
-            for (int j = 0; j < 16; j++) {
+            for (int j = 0; j < G; j++) {
                 if (!__any(c0 + j < ncols)) break;
-                col += __shfl(incl, j, 16) <= t ? 1 : 0;
+                col += __shfl(incl, j, G) <= t ? 1 : 0;
             }
-            col = min(col, 15);
-            const int bcol = __shfl(b, col, 16);
-            const int ecol = __shfl(incl - len, col, 16);
+            col = min(col, G - 1);
+            const int bcol = __shfl(b, col, G);
+            const int ecol = __shfl(incl - len, col, G);
             bool ok = false;
             int idx = -1;
             if (t < total) {
@@ -278,7 +278,7 @@ __device__ __forceinline__ int walk_window_g16(const DevFrame& f, const int* __r
                     }
                 }
             }
-            const u32 gm = (u32)(__ballot(ok) >> shift) & 0xFFFFu;
+            const u32 gm = (u32)(__ballot(ok) >> shift) & ((1u << G) - 1u);
             if (ok) emit(count + __popc(gm & ((1u << sub) - 1u)), idx);
             count += __popc(gm);
         }
@@ -428,13 +428,14 @@ __device__ __forceinline__ void projq_candidates_body(DevFrame train, const int*
     }
 }
 
-// Sixteen lanes per query; same outputs as projq_candidates_body.
-__device__ __forceinline__ void projq_candidates_g16_body(DevFrame train, const int* __restrict__ cellStart,
+// G lanes per query; same outputs as projq_candidates_body.
+template <int G>
+__device__ __forceinline__ void projq_candidates_sub_body(DevFrame train, const int* __restrict__ cellStart,
                                                           const int* __restrict__ cellItems,
                                                           const float* __restrict__ trainURight, ProjQueries q, int mode,
                                                           const int* __restrict__ offs, int* candIdx, int* candDist,
                                                           int* counts, u32* slab, int slabCap, int* overflow) {
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int i = blockIdx.x * (256 / G) + threadIdx.x / G;
     Query qq;
     qq.x = qq.y = 0.f;
     qq.r = -1.f;
@@ -445,7 +446,7 @@ __device__ __forceinline__ void projq_candidates_g16_body(DevFrame train, const 
     const bool active = inRange && projq_query(q, i, &qq);
     const u8* qd = q.desc + (i64)(inRange ? i : 0) * 32;
     const i64 rowBase = (mode == 2 && inRange) ? offs[i] : 0;
-    const int n = walk_window_g16(train, cellStart, cellItems, trainURight, qq, active, [&](int pos, int idx) {
+    const int n = walk_window_sub<G>(train, cellStart, cellItems, trainURight, qq, active, [&](int pos, int idx) {
         if (mode == 2) {
             candIdx[rowBase + pos] = idx;
             candDist[rowBase + pos] = desc_distance(qd, train.desc + (i64)idx * 32);
@@ -453,7 +454,7 @@ __device__ __forceinline__ void projq_candidates_g16_body(DevFrame train, const 
             slab[(i64)i * slabCap + pos] = ((u32)desc_distance(qd, train.desc + (i64)idx * 32) << 16) | (u32)idx;
         }
     });
-    if (inRange && (threadIdx.x & 15) == 0 && (mode == 0 || mode == 3)) {
+    if (inRange && (threadIdx.x & (G - 1)) == 0 && (mode == 0 || mode == 3)) {
         counts[i] = n;
         if (mode == 3 && n > slabCap) atomicOr(overflow, 1);
     }
@@ -695,10 +696,11 @@ __global__ __launch_bounds__(256) void k_projq_candidates_jobs(const ProjJob* __
     projq_candidates_body(J.train, J.cellStart, J.cellItems, J.trainURight, J.q, mode, J.offs, J.candIdx, J.candDist, J.counts,
                           J.slab, J.slabCap, J.overflow);
 }
-__global__ __launch_bounds__(256) void k_projq_candidates_jobs_g16(const ProjJob* __restrict__ jobs, int mode) {
+template <int G>
+__global__ __launch_bounds__(256) void k_projq_candidates_jobs_sub(const ProjJob* __restrict__ jobs, int mode) {
     const ProjJob& J = jobs[blockIdx.y];
-    if ((int)blockIdx.x * 16 >= J.q.n) return;
-    projq_candidates_g16_body(J.train, J.cellStart, J.cellItems, J.trainURight, J.q, mode, J.offs, J.candIdx, J.candDist,
+    if ((int)blockIdx.x * (256 / G) >= J.q.n) return;
+    projq_candidates_sub_body<G>(J.train, J.cellStart, J.cellItems, J.trainURight, J.q, mode, J.offs, J.candIdx, J.candDist,
                               J.counts, J.slab, J.slabCap, J.overflow);
 }
 __global__ void k_m4_queries(DevFrame cur, DevFrame last, const u8* valid, const float* u, const float* v,
@@ -2926,8 +2928,10 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
     // windows of a few grid cells (radius th * scale factor of the level) go four queries to a wave
     const bool smallWindows = th <= 15.f;
     auto launch_candidates = [&](int mode) {
-        if (smallWindows)
-            ORBM_LAUNCH(k_projq_candidates_jobs_g16, dim3((maxNl + 15) / 16, npairs), dim3(256), 0, m->stream, dJ, mode);
+        if (th <= 8.f)
+            ORBM_LAUNCH(k_projq_candidates_jobs_sub<8>, dim3((maxNl + 31) / 32, npairs), dim3(256), 0, m->stream, dJ, mode);
+        else if (smallWindows)
+            ORBM_LAUNCH(k_projq_candidates_jobs_sub<16>, dim3((maxNl + 15) / 16, npairs), dim3(256), 0, m->stream, dJ, mode);
         else
             ORBM_LAUNCH(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, mode);
     };
