@@ -2683,7 +2683,8 @@ static int run_projected(orbm_context* m, const DevFrame& train, const float* dT
     // The resolution is launched at once, on the full LDS allowance (a single workgroup runs, so the
     // size costs nothing); it declines when the problem is too large for that, which the host learns with the results.
     const size_t fixedBytes = ((size_t)nq + 1) * 4 + (size_t)nt * (8 + (pol.ratioTest ? 4 : 0) + 2) + (size_t)nq + 16;
-    if (nt <= 65536 && fixedBytes + (size_t)nq * 4 <= 150 * 1024) {
+    static const bool noAuto = getenv("ORBM_NO_AUTO") != nullptr;  // measurement knob: the route with the host round trip
+    if (!noAuto && nt <= 65536 && fixedBytes + (size_t)nq * 4 <= 150 * 1024) {
         int* dDeclined = dOverflow + 1;
         auto ka = pol.ratioTest ? k_projq_resolve_lds_auto<true> : k_projq_resolve_lds_auto<false>;
         ORBM_LAUNCH(ka, dim3(1), dim3(256), 150 * 1024, m->stream, train, q, pol, (const int*)offs, dClaim, dClaimObs, dQBest,
