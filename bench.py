@@ -83,7 +83,10 @@ def main():
     B = args.frames
     ex = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, max_width=W, max_height=H,
                       max_batch=min(args.chunk, B), device=local_rank)
-    stream = torch.cuda.current_stream()
+    # One stream for torch's work and the library's: producers (synthetic frames, fills), the
+    # library's kernels and consumers are then ordered by the stream itself.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ex.set_stream(stream.cuda_stream)
     cap = ex.max_keypoints()
 
@@ -113,6 +116,7 @@ def main():
             step()
         barrier()
         el = time.perf_counter() - t0
+        ex.synchronize()  # raises if a kernel of the device-space passes reported a capacity error
         ex.profile_enable(False)
         prof = ex.profile_read()
         if world > 1:

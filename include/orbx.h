@@ -73,9 +73,16 @@ const char* orbx_version(void);
 int orbx_create(const orbx_config* cfg, orbx_handle** out);
 void orbx_destroy(orbx_handle* h);
 
-/* Run the handle's kernels on an existing hipStream_t (NULL restores the
- * handle's own stream). */
+/* Run the handle's kernels on an existing hipStream_t.  Every value selects that stream: NULL is
+ * the legacy default stream, like any other handle.  orbx_reset_stream returns to the handle's own
+ * (non-blocking) stream.  Work the caller enqueues on the selected stream before and after a
+ * device-space call is ordered with the call's kernels. */
 int orbx_set_stream(orbx_handle* h, void* hip_stream);
+int orbx_reset_stream(orbx_handle* h);
+/* Waits for the handle's stream.  Errors that kernels of device-space calls detected since the last
+ * wait surface here: ORBX_ERR_CAPACITY when cap_per_frame was smaller than a frame's keypoint count
+ * (that frame's output was truncated to cap_per_frame entries) or a quadtree node table overflowed.
+ * The error state is cleared by the call that reports it. */
 int orbx_synchronize(orbx_handle* h);
 /* The blur of a pass depends only on the pyramid; by default it runs on a second
  * stream beside FAST + quadtree and joins before the descriptor kernel.  on = 0
@@ -99,7 +106,8 @@ int orbx_extract(orbx_handle* h, const uint8_t* img, int w, int h_, size_t strid
  * Outputs for frame f start at kps + f*cap_per_frame and desc + f*cap_per_frame*32;
  * n_out[f] receives its keypoint count.  mem_space applies to imgs, kps, desc
  * and n_out alike.  With ORBX_MEM_DEVICE the call only enqueues work on the
- * handle's stream. */
+ * handle's stream; capacity errors found by its kernels are reported by the next
+ * orbx_synchronize (or the next host-space call). */
 int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int h_,
                        size_t row_stride, size_t img_stride, orbx_keypoint* kps, uint8_t* desc,
                        int cap_per_frame, int* n_out, int mem_space);
@@ -141,8 +149,9 @@ int orbx_profile_reset(orbx_handle* h);
  * sine/cosine (radians) and fastAtan2 (degrees), n values each, host arrays. */
 int orbx_debug_sincos(orbx_handle* h, const float* angles, int n, float* sin_out, float* cos_out);
 int orbx_debug_atan2(orbx_handle* h, const float* y, const float* x, int n, float* out);
-/* Pyramid level image of frame `frame` (index in the batch of the last call, as in
- * orbx_get_level): copies w*h bytes, tightly packed, to host dst. */
+/* The taps below number frames as orbx_get_level does: `frame` is the index in the batch of the
+ * last call, and only the frames of its last pass are resident (ORBX_ERR_INVALID otherwise).
+ * Pyramid level image of frame `frame`: copies w*h bytes, tightly packed, to host dst. */
 int orbx_debug_level(orbx_handle* h, int frame, int level, uint8_t* dst);
 /* Blurred level image of frame `frame`: copies w*h bytes, tightly packed, to host dst. */
 int orbx_debug_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, int* w, int* h_);
@@ -168,7 +177,9 @@ typedef struct orbm_context orbm_context;
 /* A matcher context owns a stream and scratch on one device. */
 int orbm_create(int device, orbm_context** out);
 void orbm_destroy(orbm_context* m);
+/* Stream selection as for orbx_set_stream / orbx_reset_stream (NULL = legacy default stream). */
 int orbm_set_stream(orbm_context* m, void* hip_stream);
+int orbm_reset_stream(orbm_context* m);
 int orbm_synchronize(orbm_context* m);
 
 /* One frame's matching inputs, all arrays in the memory space given to the call. */
@@ -268,7 +279,11 @@ int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm
 /* ---- vocabulary-guided searches ----
  * DBoW2::FeatureVector (a std::map<NodeId, std::vector<unsigned int>>, reference
  * Thirdparty/DBoW2/DBoW2/FeatureVector.h) flattened to CSR: node_ids strictly ascending (map
- * order), items[start[i] .. start[i+1]) = the keypoint indices of node i in vector order. */
+ * order), items[start[i] .. start[i+1]) = the keypoint indices of node i in vector order.
+ * Every keypoint occurs in at most one node (DBoW2 files a feature under exactly one node); the
+ * kernels process nodes concurrently and rely on it.  Host-memory vectors are validated
+ * (ORBX_ERR_INVALID); with ORBX_MEM_DEVICE nothing is read back, so ascending ids, items < n and
+ * disjoint nodes are preconditions the caller guarantees. */
 typedef struct orbm_feature_vector {
     int32_t n_nodes;
     int32_t n_items;

@@ -74,6 +74,7 @@ SIGNATURES = {
     "orbx_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
     "orbx_destroy": (None, [_vp]),
     "orbx_set_stream": (_i, [_vp, _vp]),
+    "orbx_reset_stream": (_i, [_vp]),
     "orbx_synchronize": (_i, [_vp]),
     "orbx_set_overlap": (_i, [_vp, _i]),
     "orbx_max_keypoints": (_i, [_vp]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     "orbm_create": (_i, [_i, C.POINTER(_vp)]),
     "orbm_destroy": (None, [_vp]),
     "orbm_set_stream": (_i, [_vp, _vp]),
+    "orbm_reset_stream": (_i, [_vp]),
     "orbm_synchronize": (_i, [_vp]),
     "orbm_grid_build": (_i, [_vp, C.POINTER(MFrame), _vp, _vp, _i]),
     "orbm_window_candidates": (_i, [_vp, C.POINTER(MFrame), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,

@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "../../include/orbx_pattern_31.h"
@@ -1516,7 +1517,11 @@ struct orbx_handle {
     u8 *dPyr = nullptr, *dBlur = nullptr;
     u32 *dCellCount = nullptr, *dSlots = nullptr, *dKeyPacked = nullptr, *dSel = nullptr;
     u16* dKeyNode = nullptr;
-    int *dSelCount = nullptr, *dErr = nullptr;
+    int* dSelCount = nullptr;
+    // Error word of the kernels (1: quadtree node table full, 2: keypoint capacity per frame too small).
+    // It lives in pinned host memory that the device writes directly, so that reading it after a
+    // stream wait costs no copy; dErr is the device view of hErr.
+    int *hErr = nullptr, *dErr = nullptr;
     u8 *basePyr = nullptr, *baseBlur = nullptr;
     u32 *baseCellCount = nullptr, *baseSlots = nullptr, *baseKeyPacked = nullptr, *baseSel = nullptr;
     u16* baseKeyNode = nullptr;
@@ -1581,10 +1586,35 @@ void make_tables(orbx_handle* h) {
     }
 }
 
-int upload_constants() {
+const int QT_MAX_LDS = 160 * 1024 - 1024;  // dynamic LDS the quadtree kernels may ask for
+
+int upload_constants_locked();
+
+// Process-wide set-up of one device, done once under a lock however many handles and threads there
+// are: the descriptor tables go to that device's copy of d_tables and the quadtree kernels get
+// their dynamic-LDS ceiling (function attributes are per device and shared by all handles).
+int device_init_once(int device) {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= 64) {
+        orbx_set_error("device ordinal %d out of range", device);
+        return ORBX_ERR_INVALID;
+    }
+    if (done[device]) return ORBX_OK;
+    int rc = upload_constants_locked();
+    if (rc) return rc;
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<256>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_MAX_LDS));
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<512>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_MAX_LDS));
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_MAX_LDS));
+    done[device] = true;
+    return ORBX_OK;
+}
+
+int upload_constants_locked() {
     // circular patch of radius 15 (reference src/ORBextractor.cc:450-465: umax)
     static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-    static DescribeTables t;
+    DescribeTables t;
     int inside = 0;
     for (int slot = 0; slot < 248; slot++) {
         const int v = (slot >> 3) - 15, u0 = (slot & 7) * 4 - 16;
@@ -1719,7 +1749,7 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     }
     g.pyrFrameBytes = align_up((int)std::max<i64>(pyrOff, 64), 256);
     g.blurFrameBytes = align_up((int)blurOff, 256);
-    if (maxLds > 160 * 1024 - 1024) {
+    if (maxLds > (size_t)QT_MAX_LDS) {
         orbx_set_error("nfeatures too large for the quadtree's LDS budget (%zu bytes)", maxLds);
         return ORBX_ERR_UNSUPPORTED;
     }
@@ -1735,9 +1765,6 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     }
     if (const char* e = getenv("ORBX_QT_THREADS")) h->qtThreads = atoi(e);
     if (h->qtThreads != 256 && h->qtThreads != 512 && h->qtThreads != 1024) h->qtThreads = 256;
-    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
-    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
-    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxLds));
 
     // resize taps (cv::resize INTER_LINEAR, 8-bit, 11-bit fixed-point weights)
     std::vector<ResizeTap> taps;
@@ -1954,6 +1981,27 @@ struct StageTimer {
     }
 };
 
+// ORBX_RESIZE_BH=a,b,c,... forces the band height of the streaming resize for levels 1, 2, 3, ...
+// (a measurement knob).  Parsed once; the table is read-only afterwards.
+struct ForcedBands {
+    int rows[ORBX_MAX_LEVELS];
+    ForcedBands() {
+        for (int i = 0; i < ORBX_MAX_LEVELS; i++) rows[i] = 0;
+        if (const char* e = getenv("ORBX_RESIZE_BH")) {
+            int i = 1;
+            for (const char* q = e; *q && i < ORBX_MAX_LEVELS; i++) {
+                rows[i] = atoi(q);
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+        }
+    }
+};
+int forced_band_rows(int level) {
+    static const ForcedBands fb;  // initialised once, thread-safe
+    return fb.rows[level];
+}
+
 // Enqueue the whole pipeline for `n` frames starting at device image img0.
 int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc, int cap, int* dN) {
     const Geom& g = h->g;
@@ -1976,19 +2024,8 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
                 // small batches cannot fill the GPU with 32-row bands: shorter bands give more, shorter walks
                 while (bandRows > 4 && (i64)n * ((((L.w + 3) / 4) * ((L.h + bandRows - 1) / bandRows) + 255) / 256) < 1024) bandRows >>= 1;
                 {
-                    static int forced[ORBX_MAX_LEVELS] = {-1};
-                    if (forced[0] == -1) {
-                        for (int i = 0; i < ORBX_MAX_LEVELS; i++) forced[i] = 0;
-                        if (const char* e = getenv("ORBX_RESIZE_BH")) {
-                            int i = 1;
-                            for (const char* q = e; *q && i < ORBX_MAX_LEVELS; i++) {
-                                forced[i] = atoi(q);
-                                while (*q && *q != ',') q++;
-                                if (*q == ',') q++;
-                            }
-                        }
-                    }
-                    if (forced[l] > 0) bandRows = forced[l];
+                    const int forced = forced_band_rows(l);  // measurement knob
+                    if (forced > 0) bandRows = forced;
                 }
                 const int items = ((L.w + 3) / 4) * ((L.h + bandRows - 1) / bandRows);
                 dim3 grid(n, (items + 255) / 256, 1), block(256, 1, 1);
@@ -2066,13 +2103,14 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     return ORBX_OK;
 }
 
+// Waits for the handle's stream, then reads and clears the error word of the kernels.
 int check_device_error(orbx_handle* h) {
-    int e = 0;
-    ORBX_HIP_CHECK(hipMemcpyAsync(&e, h->dErr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const int e = *(volatile int*)h->hErr;
     if (e) {
-        ORBX_HIP_CHECK(hipMemsetAsync(h->dErr, 0, sizeof(int), h->stream));
-        orbx_set_error(e == 2 ? "keypoint capacity per frame too small" : "quadtree node capacity exceeded");
+        *(volatile int*)h->hErr = 0;
+        orbx_set_error(e == 2 ? "keypoint capacity per frame too small: output truncated"
+                              : "quadtree node capacity exceeded");
         return ORBX_ERR_CAPACITY;
     }
     return ORBX_OK;
@@ -2108,7 +2146,7 @@ int orbx_create(const orbx_config* cfg, orbx_handle** out) {
     h->cfg = *cfg;
     h->device = cfg->device;
     make_tables(h);
-    int rc = upload_constants();
+    int rc = device_init_once(cfg->device);
     if (rc == ORBX_OK && hipStreamCreateWithFlags(&h->ownStream, hipStreamNonBlocking) != hipSuccess) {
         orbx_set_error("hipStreamCreate failed");
         rc = ORBX_ERR_HIP;
@@ -2120,10 +2158,14 @@ int orbx_create(const orbx_config* cfg, orbx_handle** out) {
         orbx_set_error("hipStreamCreate/hipEventCreate failed");
         rc = ORBX_ERR_HIP;
     }
-    if (rc == ORBX_OK && (hipMalloc((void**)&h->dErr, sizeof(int)) != hipSuccess ||
-                          hipMemset(h->dErr, 0, sizeof(int)) != hipSuccess)) {
-        orbx_set_error("hipMalloc failed");
-        rc = ORBX_ERR_HIP;
+    if (rc == ORBX_OK) {
+        if (hipHostMalloc((void**)&h->hErr, 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&h->dErr, h->hErr, 0) != hipSuccess) {
+            orbx_set_error("hipHostMalloc failed");
+            rc = ORBX_ERR_HIP;
+        } else {
+            *h->hErr = 0;
+        }
     }
     if (rc == ORBX_OK) rc = compute_geometry(h, cfg->max_width, cfg->max_height);
     if (rc == ORBX_OK) rc = ensure_scratch(h, cfg->max_batch);
@@ -2138,7 +2180,6 @@ int orbx_create(const orbx_config* cfg, orbx_handle** out) {
 void orbx_destroy(orbx_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipDeviceSynchronize();
     free_dev(h->basePyr); free_dev(h->baseBlur); free_dev(h->baseCellCount); free_dev(h->baseSlots);
     free_dev(h->baseKeyPacked); free_dev(h->baseKeyNode); free_dev(h->baseSel); free_dev(h->baseSelCount);
@@ -2151,7 +2192,8 @@ void orbx_destroy(orbx_handle* h) {
         if (P.evDone) (void)hipEventDestroy(P.evDone);
     }
     if (h->evStart) (void)hipEventDestroy(h->evStart);
-    free_dev(h->dErr); free_dev(h->dTaps); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dRawStage); free_dev(h->dKpStage);
+    if (h->hErr) (void)hipHostFree(h->hErr);
+    free_dev(h->dTaps); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dRawStage); free_dev(h->dKpStage);
     free_dev(h->dDescStage); free_dev(h->dNStage);
     for (int s = 0; s < ORBX_STAGE_COUNT; s++)
         for (auto& e : h->prof.ev[s]) {
@@ -2171,7 +2213,14 @@ void orbx_destroy(orbx_handle* h) {
 int orbx_set_stream(orbx_handle* h, void* hip_stream) {
     if (!h) return ORBX_ERR_INVALID;
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->ownStream;
+    h->stream = (hipStream_t)hip_stream;  // NULL is the legacy default stream, like any other handle
+    return ORBX_OK;
+}
+
+int orbx_reset_stream(orbx_handle* h) {
+    if (!h) return ORBX_ERR_INVALID;
+    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->stream = h->ownStream;
     return ORBX_OK;
 }
 
@@ -2184,8 +2233,7 @@ int orbx_set_overlap(orbx_handle* h, int on) {
 
 int orbx_synchronize(orbx_handle* h) {
     if (!h) return ORBX_ERR_INVALID;
-    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-    return ORBX_OK;
+    return check_device_error(h);
 }
 
 int orbx_max_keypoints(const orbx_handle* h) { return h ? h->g.totalSel : 0; }
@@ -2452,6 +2500,18 @@ int orbx_debug_atan2(orbx_handle* h, const float* y, const float* x, int n, floa
     return ORBX_OK;
 }
 
+// Index of `frame` (numbered within the last call, as in orbx_get_level) inside the last pass,
+// whose stage outputs are the ones still resident; -1 when it is not.
+static int resident_frame(orbx_handle* h, int frame) {
+    const int fl = frame - h->lastFirstFrame;
+    if (fl < 0 || fl >= h->lastBatch) {
+        orbx_set_error("frame %d is not resident (last pass held frames %d..%d)", frame, h->lastFirstFrame,
+                       h->lastFirstFrame + h->lastBatch - 1);
+        return -1;
+    }
+    return fl;
+}
+
 int orbx_debug_level(orbx_handle* h, int frame, int level, uint8_t* dst) {
     const uint8_t* ptr = nullptr;
     int w = 0, hh = 0;
@@ -2464,8 +2524,8 @@ int orbx_debug_level(orbx_handle* h, int frame, int level, uint8_t* dst) {
 }
 
 int orbx_debug_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, int* w, int* hh) {
-    if (!h || !dst || !h->geomValid || level < 0 || level >= h->g.nlevels || frame < 0 || frame >= h->lastBatch)
-        return ORBX_ERR_INVALID;
+    if (!h || !dst || !h->geomValid || level < 0 || level >= h->g.nlevels) return ORBX_ERR_INVALID;
+    if ((frame = resident_frame(h, frame)) < 0) return ORBX_ERR_INVALID;
     const LevelGeom& L = h->g.lv[level];
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
     ORBX_HIP_CHECK(hipMemcpy2D(dst, L.w, h->dBlur + (i64)frame * h->g.blurFrameBytes + L.blurOff, L.blurPitch, L.w,
@@ -2476,8 +2536,8 @@ int orbx_debug_blurred(orbx_handle* h, int frame, int level, uint8_t* dst, int* 
 }
 
 int orbx_debug_candidates(orbx_handle* h, int frame, int level, int* xs, int* ys, int* resp, int cap, int* n) {
-    if (!h || !n || !h->geomValid || level < 0 || level >= h->g.nlevels || frame < 0 || frame >= h->lastBatch)
-        return ORBX_ERR_INVALID;
+    if (!h || !n || !h->geomValid || level < 0 || level >= h->g.nlevels) return ORBX_ERR_INVALID;
+    if ((frame = resident_frame(h, frame)) < 0) return ORBX_ERR_INVALID;
     const Geom& g = h->g;
     const LevelGeom& L = g.lv[level];
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -2503,8 +2563,8 @@ int orbx_debug_candidates(orbx_handle* h, int frame, int level, int* xs, int* ys
 }
 
 int orbx_debug_selected(orbx_handle* h, int frame, int level, int* xs, int* ys, int* resp, int cap, int* n) {
-    if (!h || !n || !h->geomValid || level < 0 || level >= h->g.nlevels || frame < 0 || frame >= h->lastBatch)
-        return ORBX_ERR_INVALID;
+    if (!h || !n || !h->geomValid || level < 0 || level >= h->g.nlevels) return ORBX_ERR_INVALID;
+    if ((frame = resident_frame(h, frame)) < 0) return ORBX_ERR_INVALID;
     const Geom& g = h->g;
     const LevelGeom& L = g.lv[level];
     ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));

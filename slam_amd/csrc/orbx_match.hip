@@ -2154,7 +2154,7 @@ struct orbm_context {
     // grow-only scratch, one block per purpose
     std::vector<std::pair<void*, size_t>> pool;
     std::vector<int> totalsHost;
-    bool resolveLdsReady = false, resolveJobsLdsReady = false, initSortedReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
+    bool resolveLdsReady = false, resolveJobsLdsReady = false, initSortedReady = false, distinctiveReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
     // Host arrays travel through one pinned arena per call: copies from and to pageable memory are staged
     // and serialised by the runtime (10-15 us each), copies from pinned memory are plain queue entries.
     // Results land in the arena and are handed to the caller's arrays after the stream has been waited for.
@@ -2476,7 +2476,14 @@ void orbm_destroy(orbm_context* m) {
 int orbm_set_stream(orbm_context* m, void* hip_stream) {
     if (!m) return ORBX_ERR_INVALID;
     ORBX_HIP_CHECK(sync_deliver(m));
-    m->stream = hip_stream ? (hipStream_t)hip_stream : m->ownStream;
+    m->stream = (hipStream_t)hip_stream;  // NULL is the legacy default stream, like any other handle
+    return ORBX_OK;
+}
+
+int orbm_reset_stream(orbm_context* m) {
+    if (!m) return ORBX_ERR_INVALID;
+    ORBX_HIP_CHECK(sync_deliver(m));
+    m->stream = m->ownStream;
     return ORBX_OK;
 }
 
@@ -3093,7 +3100,9 @@ static int make_featvec(orbm_context* m, const orbm_feature_vector* fv, int slot
     return ORBX_OK;
 }
 
-// host-side checks on a host-memory feature vector: ascending ids, monotone offsets, items in range
+// host-side checks on a host-memory feature vector: ascending ids, monotone offsets, items in range,
+// and every keypoint in at most one node (DBoW2 files each feature under exactly one node; the
+// kernels run the nodes concurrently and rely on their keypoint sets being disjoint)
 static int check_featvec_host(const orbm_feature_vector* fv, int nKeypoints) {
     for (int i = 0; i < fv->n_nodes; i++) {
         if (i > 0 && fv->node_ids[i] <= fv->node_ids[i - 1]) {
@@ -3105,11 +3114,18 @@ static int check_featvec_host(const orbm_feature_vector* fv, int nKeypoints) {
             return ORBX_ERR_INVALID;
         }
     }
-    for (int i = 0; i < fv->n_items; i++)
+    std::vector<bool> seen((size_t)std::max(nKeypoints, 1), false);
+    for (int i = 0; i < fv->n_items; i++) {
         if (fv->items[i] >= (uint32_t)nKeypoints) {
             orbx_set_error("feature vector: item %d names keypoint %u of %d", i, fv->items[i], nKeypoints);
             return ORBX_ERR_INVALID;
         }
+        if (seen[fv->items[i]]) {
+            orbx_set_error("feature vector: keypoint %u occurs more than once", fv->items[i]);
+            return ORBX_ERR_INVALID;
+        }
+        seen[fv->items[i]] = true;
+    }
     return ORBX_OK;
 }
 
@@ -3377,11 +3393,11 @@ int orbm_distinctive_descriptors(orbm_context* m, const uint8_t* desc, const int
     if ((rc = stage_out(m, SL_DD_BEST, (int*)best, (size_t)ngroups, mem_space, &dBest))) return rc;
     if (best_median && (rc = stage_out(m, SL_DD_MED, (int*)best_median, (size_t)ngroups, mem_space, &dMed))) return rc;
     if (out_desc && (rc = stage_out(m, SL_DD_OUT, out_desc, (size_t)ngroups * 32, mem_space, &dOut))) return rc;
-    static bool attrSet = false;
     const int ldsBytes = 4 * DD_MAX_GROUP * (int)sizeof(u16);
-    if (!attrSet) {
+    if (!m->distinctiveReady) {
+        // per context (function attributes are per device; every context sets the same constant)
         ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_distinctive, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
-        attrSet = true;
+        m->distinctiveReady = true;
     }
     ORBM_LAUNCH(k_distinctive, dim3((ngroups + 3) / 4), dim3(256), ldsBytes, m->stream, dDesc, dStart, ngroups, dBest,
                        dMed, dOut);

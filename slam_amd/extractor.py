@@ -112,7 +112,11 @@ class ORBextractor:
                                            n_out.data_ptr(), MEM_DEVICE))
 
     def set_stream(self, stream_ptr):
-        check(self._lib.orbx_set_stream(self._h, C.c_void_p(stream_ptr)))
+        """Run on the hipStream_t with this handle value (0 / None = the legacy default stream)."""
+        check(self._lib.orbx_set_stream(self._h, C.c_void_p(stream_ptr or None)))
+
+    def reset_stream(self):
+        check(self._lib.orbx_reset_stream(self._h))
 
     def set_overlap(self, on):
         check(self._lib.orbx_set_overlap(self._h, int(bool(on))))

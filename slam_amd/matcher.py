@@ -469,7 +469,11 @@ class ORBmatcher:
         return (b <= th) & (b.astype(np.float32) < np.float32(self.mfNNratio) * s.astype(np.float32))
 
     def set_stream(self, stream_ptr):
-        check(self._lib.orbm_set_stream(self._m, C.c_void_p(stream_ptr)))
+        """Run on the hipStream_t with this handle value (0 / None = the legacy default stream)."""
+        check(self._lib.orbm_set_stream(self._m, C.c_void_p(stream_ptr or None)))
+
+    def reset_stream(self):
+        check(self._lib.orbm_reset_stream(self._m))
 
     def synchronize(self):
         check(self._lib.orbm_synchronize(self._m))

@@ -108,6 +108,11 @@ def test_search_by_bow_disjoint_and_empty(oracle, pair, matcher):
     from slam_amd._lib import OrbxError
     with pytest.raises(OrbxError):
         matcher.SearchByBoW(ga, {1: [len(pair["ka"]) + 5]}, v, gb, fvb)   # item outside the frame
+    # a keypoint filed under two nodes would make the result depend on scheduling: rejected
+    with pytest.raises(OrbxError):
+        matcher.SearchByBoW(ga, fva, v, gb, {3: [0, 1], 9: [1, 2]})
+    with pytest.raises(OrbxError):
+        matcher.SearchByBoW(ga, {2: [0, 1, 0]}, v, gb, fvb)
 
 
 @pytest.mark.parametrize("only_stereo,ori", [(False, True), (True, True), (False, False)])

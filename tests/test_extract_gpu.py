@@ -378,3 +378,99 @@ def test_two_extractors_from_two_threads(oracle):
     for ex in exs:
         ex.close()
     assert not errors, errors
+
+
+def test_device_capacity_error_surfaces_at_synchronize(extractor_vga):
+    """A device-space batch only enqueues work, so a capacity below a frame's keypoint count
+    cannot be reported by the call itself: the next synchronize reports it, once."""
+    import torch
+    from slam_amd._lib import OrbxError
+    ex = extractor_vga
+    frames = synth.synth_batch_torch(3, 640, 480, 8100, device="cuda")
+    cap = 100   # far below the ~1000 keypoints of a textured frame
+    d_kps = torch.zeros(3 * cap * 28, dtype=torch.uint8, device="cuda")
+    d_desc = torch.zeros(3 * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(3, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ex.extract_batch_device(frames, d_kps, d_desc, d_n, cap)
+    with pytest.raises(OrbxError) as e:
+        ex.synchronize()
+    assert "-4" in str(e.value) and "capacity" in str(e.value)
+    assert (d_n.cpu().numpy() == cap).all()      # truncated, never written past the capacity
+    ex.synchronize()                             # the error state was cleared by the call that reported it
+    # an unrelated host-space call afterwards is not affected
+    kps, desc = ex(synth.synth_image(640, 480, 1), None)
+    assert len(kps) >= 1000
+
+
+def test_torch_work_and_library_share_a_stream_without_manual_waits(oracle):
+    """The library runs on the stream it is given (the legacy default stream included), so work
+    that torch enqueues on that stream before and after a device-space call is ordered with it:
+    no synchronize between producer, library and consumer."""
+    import torch
+    from slam_amd._lib import KP_DTYPE
+    from slam_amd.extractor import ORBextractor
+    host = synth.synth_batch(4, 640, 480, 8200)
+    p = oracle.params()
+    want = [oracle.extract(p, host[f]) for f in range(4)]
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=2)
+    try:
+        cap = ex.max_keypoints()
+        for stream in (torch.cuda.Stream(), torch.cuda.default_stream()):
+            ex.set_stream(stream.cuda_stream)
+            with torch.cuda.stream(stream):
+                pinned = torch.from_numpy(host).pin_memory()
+                # producer: an upload and a chain of device ops that end in the frames
+                noise = torch.randint(0, 255, (64, 4, 480, 640), dtype=torch.uint8, device="cuda")
+                frames = pinned.cuda(non_blocking=True)
+                for k in range(64):
+                    frames = frames ^ noise[k]
+                for k in range(64):
+                    frames = frames ^ noise[k]
+                d_kps = torch.empty(4 * cap * 28, dtype=torch.uint8, device="cuda")
+                d_desc = torch.empty(4 * cap * 32, dtype=torch.uint8, device="cuda")
+                d_n = torch.empty(4, dtype=torch.int32, device="cuda")
+                ex.extract_batch_device(frames, d_kps, d_desc, d_n, cap)
+                # consumers on the same stream
+                n_copy = d_n.clone()
+                desc_sum = d_desc.view(4, cap, 32).to(torch.int64).sum()
+                kps_host = d_kps.cpu()
+                desc_host = d_desc.cpu()
+                n = n_copy.cpu().numpy()
+            kps = kps_host.numpy().view(KP_DTYPE).reshape(4, cap)
+            desc = desc_host.numpy().reshape(4, cap, 32)
+            for f in range(4):
+                rk, rd = want[f]
+                assert_same_features(kps[f, :n[f]], desc[f, :n[f]], rk, rd, "frame %d" % f)
+            assert int(desc_sum.item()) == int(desc.astype(np.int64).sum())
+        ex.reset_stream()
+    finally:
+        ex.close()
+
+
+def test_debug_taps_number_frames_like_get_level(oracle):
+    """With a batch longer than max_batch only the last pass stays resident; every tap takes the
+    frame index within the whole call and refuses frames of earlier passes."""
+    from slam_amd._lib import OrbxError
+    from slam_amd.extractor import ORBextractor
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=2)
+    try:
+        imgs = synth.synth_batch(5, 640, 480, 8300)   # passes: frames 0-1, 2-3, 4
+        ex.extract_batch(imgs)
+        p = oracle.params()
+        ref = oracle.pyramid_level(p, imgs[4], 2)
+        assert np.array_equal(ex.image_pyramid_level(4, 2), ref)
+        assert np.array_equal(ex.debug_blurred(4, 2), oracle.gaussian7(ref))
+        rx, ry, rr = oracle.detect_cells(ref)
+        gx, gy, gr = ex.debug_candidates(4, 2)
+        assert np.array_equal(gx, rx) and np.array_equal(gy, ry) and np.array_equal(gr, rr)
+        sx, sy, sr = ex.debug_selected(4, 2)
+        h, w = ref.shape
+        sel = oracle.distribute(rx, ry, rr, 16, w - 16, 16, h - 16, int(ex.features_per_level()[2]))
+        assert np.array_equal(sx, rx[sel] + 16) and np.array_equal(sy, ry[sel] + 16)
+        for tap in (lambda: ex.image_pyramid_level(0, 2), lambda: ex.debug_blurred(3, 2),
+                    lambda: ex.debug_candidates(1, 2), lambda: ex.debug_selected(5, 2)):
+            with pytest.raises(OrbxError):
+                tap()
+    finally:
+        ex.close()
