@@ -430,6 +430,17 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
               int train_index_base, int32_t* best_idx, int32_t* best_d, int32_t* second_d,
               int mem_space);
 
+/* orbm_knn2 for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same results as
+ * orbm_knn2 with ORBX_MEM_DEVICE (q, t and the three outputs are device arrays, q and t 16-byte
+ * aligned); the call only enqueues kernels on the context's stream and calls no hipMalloc,
+ * hipFree or other allocating routine.  Its partial results live in a 12 MiB array that is part
+ * of the library's code object on every GPU it runs on.  Limits: nq <= 1048576 and nt <= 4194304
+ * (ORBX_ERR_CAPACITY beyond).  All calls on one GPU share that array: calls that overlap in time
+ * on one GPU (two contexts, two streams) race and must be serialised by the caller. */
+int orbm_knn2_noalloc(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                      int train_index_base, int32_t* best_idx, int32_t* best_d, int32_t* second_d);
+
 /* Merge two partial kNN-2 results for the same queries (shard A precedes shard
  * B in global train order): reproduces the serial scan over A then B. */
 int orbm_knn2_merge(orbm_context* m, int nq, int32_t* best_idx_a, int32_t* best_d_a,

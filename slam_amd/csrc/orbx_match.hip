@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "orbx_internal.h"
@@ -2147,6 +2148,40 @@ __global__ void k_knn2_merge_slices(int nq, int nSlices, const int* pi, const in
 
 }  // namespace
 
+// ------------------------------------------------------------------ no-allocation 2-NN scratch
+// Partial results of orbm_knn2_noalloc: three arrays (best index, best distance, second
+// distance) of KNN_NA_MAX_PART entries each, one entry per (train slice, query).  12 MiB that
+// every GPU the library runs on holds until the process ends.  The array's name is only a host-side
+// stand-in; host code uses the per-device address fetched with hipGetSymbolAddress.
+#define KNN_NA_MAX_PART (1 << 20)
+static __device__ __align__(256) int scratch[3 * KNN_NA_MAX_PART];
+
+namespace {
+const int MAX_DEVICES = 64;
+std::mutex g_scratchMu;
+int* g_scratchPtr[MAX_DEVICES] = {nullptr};  // device address of `scratch` on each GPU
+
+// With `device` current: the address of that GPU's copy of `scratch`, looked up once.
+int scratch_address(int device, int** out) {
+    if (device < 0 || device >= MAX_DEVICES) {
+        orbx_set_error("device ordinal %d out of range", device);
+        return ORBX_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> lock(g_scratchMu);
+    if (!g_scratchPtr[device]) {
+        void* p = nullptr;
+        ORBX_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) {
+            orbx_set_error("hipGetSymbolAddress returned a null address");
+            return ORBX_ERR_HIP;
+        }
+        g_scratchPtr[device] = (int*)p;
+    }
+    *out = g_scratchPtr[device];
+    return ORBX_OK;
+}
+}  // namespace
+
 // ------------------------------------------------------------------ host
 struct orbm_context {
     int device = 0;
@@ -2170,6 +2205,7 @@ struct orbm_context {
     // Result arrays live in the mirror too: the pieces asked back are fetched at the next wait, neighbours in one copy.
     std::vector<std::pair<size_t, size_t>> downloads;  // (offset, bytes) in the current arena
     hipError_t asyncError = hipSuccess;  // first failure of a deferred upload, reported by the next wait
+    int* naScratch = nullptr;  // this device's copy of the static scratch array (orbm_knn2_noalloc)
     struct Delivery {
         void* dst;
         const void* src;
@@ -2455,6 +2491,13 @@ int orbm_create(int device, orbm_context** out) {
         return ORBX_ERR_HIP;
     }
     m->stream = m->ownStream;
+    // set-up of the no-allocation entry point: this device is current here
+    const int rcs = scratch_address(device, &m->naScratch);
+    if (rcs != ORBX_OK) {
+        (void)hipStreamDestroy(m->ownStream);
+        delete m;
+        return rcs;
+    }
     *out = m;
     return ORBX_OK;
 }
@@ -3547,6 +3590,53 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
     if ((rc = copy_back(m, (int*)best_d, (const int*)dd, (size_t)nq, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)second_d, (const int*)ds, (size_t)nq, mem_space))) return rc;
     if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
+    return ORBX_OK;
+}
+
+int orbm_knn2_noalloc(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int train_index_base,
+                      int32_t* best_idx, int32_t* best_d, int32_t* second_d) {
+    // Nothing here allocates or frees: no arena, no pool, no staging.  The train rows are always
+    // split over blockIdx.y; every slice writes its partials for all queries into the static
+    // scratch array (each entry is written before it is read, so nothing needs clearing), and the
+    // merge kernel folds them in slice order into the caller's arrays.
+    if (!m) {
+        orbx_set_error("null context");
+        return ORBX_ERR_INVALID;
+    }
+    if (nq < 0 || nt < 0 || !best_idx || !best_d || !second_d || (nq > 0 && !q) || (nt > 0 && !t)) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (nq == 0) return ORBX_OK;
+    if (nq > KNN_NA_MAX_PART) {
+        orbx_set_error("orbm_knn2_noalloc: %d queries exceed the limit of %d", nq, KNN_NA_MAX_PART);
+        return ORBX_ERR_CAPACITY;
+    }
+    if (nt > (1 << KNN_IDX_BITS)) {
+        orbx_set_error("orbm_knn2_noalloc: %d train rows exceed the limit of %d", nt, 1 << KNN_IDX_BITS);
+        return ORBX_ERR_CAPACITY;
+    }
+    if (((uintptr_t)q | (uintptr_t)t) & 15u) {
+        orbx_set_error("device descriptor arrays must be 16-byte aligned");
+        return ORBX_ERR_INVALID;
+    }
+    ORBX_HIP_CHECK(hipSetDevice(m->device));
+    int* const base = m->naScratch;  // the device address, never the array's name
+    if (!base) {
+        orbx_set_error("scratch address missing");
+        return ORBX_ERR_HIP;
+    }
+    int *pi = base, *pd = base + KNN_NA_MAX_PART, *ps = base + 2 * KNN_NA_MAX_PART;
+    const int blocks = (nq + 256 * KNN_QPT - 1) / (256 * KNN_QPT);
+    int slices = std::min(nt / 32, std::max(1024 / blocks, 1));
+    slices = std::max(std::min(slices, KNN_NA_MAX_PART / nq), 1);
+    const int sliceRows = std::max(((nt + slices - 1) / slices + 7) & ~7, 8);
+    slices = std::max((nt + sliceRows - 1) / sliceRows, 1);
+    hipLaunchKernelGGL(k_knn2, dim3(blocks, slices), dim3(256), 0, m->stream, (const uint4*)q, nq, (const uint4*)t, nt,
+                       train_index_base, pi, pd, ps, 0, sliceRows);
+    hipLaunchKernelGGL(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, slices, (const int*)pi,
+                       (const int*)pd, (const int*)ps, (int*)best_idx, (int*)best_d, (int*)second_d);
+    ORBX_HIP_CHECK(hipGetLastError());
     return ORBX_OK;
 }
 

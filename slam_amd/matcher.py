@@ -447,6 +447,12 @@ class ORBmatcher:
                                   index_base, best_idx.data_ptr(), best_d.data_ptr(),
                                   second_d.data_ptr(), _lib.MEM_DEVICE))
 
+    def knn2_noalloc_device(self, q, t, best_idx, best_d, second_d, index_base=0):
+        """knn2_device through the entry point that allocates nothing (static device scratch)."""
+        check(self._lib.orbm_knn2_noalloc(self._m, q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0],
+                                          index_base, best_idx.data_ptr(), best_d.data_ptr(),
+                                          second_d.data_ptr()))
+
     def knn2_merge_device(self, ia, da, sa, ib, db, sb):
         check(self._lib.orbm_knn2_merge(self._m, ia.shape[0], ia.data_ptr(), da.data_ptr(),
                                         sa.data_ptr(), ib.data_ptr(), db.data_ptr(), sb.data_ptr(),
