@@ -59,6 +59,7 @@ struct Geom {
     int nlevels, w, h;
     int totalCells, totalSlots, totalSel, totalBlurTiles, totalBlurItems;
     int fastRoiPitch, fastPlaneOff, fastQueueOff, fastLdsBytes;  // k_fast LDS carve-up
+    u32 fastRoiMagic;                                            // div_magic(fastRoiPitch)
     i64 pyrFrameBytes, blurFrameBytes;
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
@@ -480,8 +481,6 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
 }
 
 // ------------------------------------------------------------------ FAST
-#define ROI_MAX (MAX_CELL + 6)
-
 __device__ __forceinline__ int wave_excl_count(bool flag, int* total) {
     const u64 m = __ballot(flag);
     *total = __popcll(m);
@@ -489,59 +488,38 @@ __device__ __forceinline__ int wave_excl_count(bool flag, int* total) {
     return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
 }
 
-// FAST-9/16 strength of a pixel: M = max over the 16 arcs of 9 contiguous ring
-// pixels of the arc minimum of (v - p) [darker] or (p - v) [brighter].  The
-// pixel is a corner for threshold t iff M > t, and its response is M - 1.
-__device__ __forceinline__ int fast_strength(const int* d) {
-    // d[k] = v - ring[k], k = 0..15
-    int mn3[16], mx3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mn3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-        mx3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-    }
-    int dark = -256, bright_neg = 256;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int mn9 = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
-        const int mx9 = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
-        dark = max(dark, mn9);
-        bright_neg = min(bright_neg, mx9);
-    }
-    return max(dark, -bright_neg);
-}
-
 // floor(i / d) for i, d < 65536 with magic = floor(2^32 / d) + 1 (d >= 2).
 __device__ __forceinline__ u32 fastdiv(u32 i, u32 d, u32 magic) { return d == 1 ? i : __umulhi(i, magic); }
 __host__ __device__ __forceinline__ u32 div_magic(u32 d) { return d <= 1 ? 0u : (u32)(0x100000000ull / d) + 1u; }
 
 // Per-cell constants, computed on the host when the geometry is set up so that a wave
-// starts without divisions or level searches.
-//   w0 = level | roi width << 8 | roi height << 16      w1 = iniX | iniY << 16
-//   w2 = slot offset inside the frame's slot block        w3 = slot capacity | nk << 16 | (64 / nk) << 24
+// starts without divisions, level searches or pyramid address arithmetic.
+//   w0 = level | roi width << 8 | roi height << 16 | (iniX & 3) << 24
+//   w1 = iniX | iniY << 16
+//   w2 = slot offset inside the frame's slot block
+//   w3 = slot capacity | nk << 16 | (64 / nk) << 24
 //   w4 = gx0 | gy0 << 16 (detection-origin coordinates of the first interior pixel)
-//   w5 = magic(nW)   w6 = magic(nk)   w7 = nW | (64 / nW) << 8
-// nW = 32-bit words per ROI row when rows are fetched from a 4-byte aligned address,
-// nk = words per row that hold interior pixels in that layout.
+//   w5 = magic(nWc)   w6 = magic(nk)   w7 = nWc | (64 / nWc) << 8
+//   w8 = byte offset of (iniY, iniX & ~3) inside the per-frame pyramid block (levels >= 1)
+//   w9 = row pitch of the level (levels >= 1)   w10 = magic(roi width)   w11 = 0
+// nk = 32-bit words per row that hold interior pixels when interior pixel 0 sits on a word
+// boundary, nWc = nk + 2 = words copied per ROI row (one before, one after).
 struct FastCell {
-    u32 w[8];
+    u32 w[12];
 };
 
-
-// Bytes 1 and 3 of a word as two 16-bit values (one packed 16-bit shift).
-__device__ __forceinline__ u32 odd_bytes(u32 w) { return as_u32(as_u16x2(w) >> (u16x2)(8)); }
-
-// Necessary condition for a FAST-9 corner on two pixels at once (16-bit halves): with
-// u/d/l/r the ring pixels 3 above, below, left and right of v, a 9-arc holds one pixel of
-// each opposite pair, so   max(min(u,d), min(l,r)) + th < v   (darker arc)   or
-// v + th < min(max(u,d), max(l,r))   (brighter arc)   must hold.  Returns the two sign bits.
-__device__ __forceinline__ u32 pair_test2(u32 v, u32 u, u32 d, u32 l, u32 r, u32 th2) {
-    const u16x2 V = as_u16x2(v), U = as_u16x2(u), D = as_u16x2(d), Lp = as_u16x2(l), Rp = as_u16x2(r), T = as_u16x2(th2);
-    const u16x2 A = __builtin_elementwise_max(__builtin_elementwise_min(U, D), __builtin_elementwise_min(Lp, Rp));
-    const u16x2 B = __builtin_elementwise_min(__builtin_elementwise_max(U, D), __builtin_elementwise_max(Lp, Rp));
-    const u16x2 t1 = (A + T) - V;  // negative iff A + th < v
-    const u16x2 t2 = (V + T) - B;  // negative iff v + th < B
-    return (as_u32(t1) | as_u32(t2)) & 0x80008000u;
+// v_pk_minimum3_f16 / v_pk_maximum3_f16: three-input minimum / maximum on both 16-bit halves.
+// Used on bit patterns 0x0401..0x05FF only: positive normal half floats of one exponent, whose
+// order is the order of the patterns, so the result is the integer minimum / maximum of each half.
+__device__ __forceinline__ u32 pk_min3h(u32 a, u32 b, u32 c) {
+    u32 r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ u32 pk_max3h(u32 a, u32 b, u32 c) {
+    u32 r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 // Inclusive prefix sum over the 64 lanes with DPP adds: Hillis-Steele inside each row of 16
@@ -556,193 +534,370 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     return v;
 }
 
-// One wave per cell.  ROI -> LDS (aligned 32-bit loads), then a cascade:
-//   1. the pair test above on 4 pixels per lane (one LDS word and its four neighbour
-//      words); survivors queued in raster order as (y << 8 | x),
-//   2. full strength for queued pixels; pixels above the threshold are written to the
-//      strength plane and re-queued (still raster order),
-//   3. non-max suppression over the queue; survivors written in raster order to the
-//      cell's slot range.
+#ifdef ORBX_FAST_DIAG
+// Diagnostic build only (tools/probe/fast_phases.py): every wave writes one record of 8 words:
+// cycles of the five phases (copy, pair test, expansion + strength, NMS, tail), then
+// n1 | n2 << 32, survivors | second-threshold << 32, flagged words.  Plain stores: atomics on
+// shared counters would dominate the kernel.
+__device__ unsigned long long* d_fastDiag;
+#define FAST_STAMP(i)                                                        \
+    do {                                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        diagT[i] += now_ - diagLast;                                         \
+        diagLast = now_;                                                     \
+    } while (0)
+#else
+#define FAST_STAMP(i)
+#endif
+
+// One wave per cell.  The ROI goes to LDS with interior pixel 0 on a word boundary (byte 4 of
+// its row), then a cascade, all of it in raster order:
+//   1. a necessary condition for a FAST-9 corner on 4 pixels per lane: with u/d/l/r the ring
+//      pixels 3 above, below, left and right of v, a 9-arc holds one pixel of each opposite
+//      pair, so (u or d darker than v - th) and (l or r darker), or the same with brighter,
+//      must hold.  Two pixels per 32-bit operation in 16-bit fields, comparisons as sign bits
+//      of biased sums (adds and bitwise operations only, which issue at twice the rate of the
+//      packed minimum / maximum forms).  Words with a surviving pixel are queued with a wave
+//      ballot (one store per word);
+//   2. the word queue is expanded to a pixel queue (byte offset of the pixel in the ROI);
+//   3. full 16-arc strength for queued pixels, two pixels per lane in the two halves of
+//      packed registers (three-input packed minimum / maximum); pixels above the threshold are
+//      written to the strength plane (same geometry as the ROI) and re-queued;
+//   4. non-max suppression over the queue; survivors written to the cell's slot range.
 // The cascade runs at iniTh and is repeated at minTh only when nothing survived (the
 // reference's per-cell fallback).  A single wave executes LDS operations in program order,
 // so the phases need no workgroup barrier beyond the compiler-level ordering of
 // __syncthreads().
+#define FAST_CPW 1  // cells per wave: the ROI of the next cell is fetched into registers while the current one is worked on
+
+struct __attribute__((packed, aligned(4))) FastPair {
+    u32 a, b;
+};
+
 __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligned, const u8* __restrict__ pyr,
                                               const FastCell* __restrict__ cells, u32* __restrict__ cellCount,
                                               u32* __restrict__ slots, int iniTh, int minTh) {
     extern __shared__ __align__(16) u8 lds[];
     u8* roi = lds;
     u8* plane = lds + g.fastPlaneOff;
+    u32* wq = (u32*)plane;  // the word queue is dead before the plane is cleared
     u16* queue = (u16*)(lds + g.fastQueueOff);
     // blockIdx.x = frame: with a batch that is a multiple of 8 all cells of a frame run on one
     // XCD, so the halo rows and cache lines that neighbouring cells share come from its L2.
     const int f = blockIdx.x;
-    const int cell = blockIdx.y;
+    const int cell0 = blockIdx.y * FAST_CPW;
     const int lane = threadIdx.x;
-    const FastCell C = cells[cell];
-    const int l = C.w[0] & 255, rw = (C.w[0] >> 8) & 255, rh = (C.w[0] >> 16) & 255;
-    const int iniX = C.w[1] & 0xffff, iniY = C.w[1] >> 16;
-    const int cellCap = C.w[3] & 0xffff;
-    u32* cnt = cellCount + (i64)f * g.totalCells + cell;
-    if (rw < 7 || rh < 7) {
-        if (lane == 0) *cnt = 0;
-        return;
-    }
     const int RP = g.fastRoiPitch;
-    const ImgRef im = level_image(g, l, img0, pyr);
-    const int iw = rw - 6, ih = rh - 6, pw = iw + 2;
-    int xo = 0, nk, rowsPer;
-    u32 mgk;
-    if (l > 0 || img0Aligned) {
-        const int xa = iniX & ~3;
-        xo = iniX - xa;
-        const int nW = (int)(C.w[7] & 255), rowsW = (int)((C.w[7] >> 8) & 255);
-        const u32 mg = C.w[5];
-        nk = (int)((C.w[3] >> 16) & 255);
-        rowsPer = (int)(C.w[3] >> 24);
-        mgk = C.w[6];
-        // a lane copies word wd of row lw inside a group of rowsW rows, group after group
-        const int lw = (int)fastdiv((u32)lane, (u32)nW, mg), wd = lane - lw * nW;
+#ifdef ORBX_FAST_DIAG
+    unsigned long long diagT[5] = {0, 0, 0, 0, 0}, diagLast = __builtin_amdgcn_s_memtime();
+    int diagN1 = 0, diagN2 = 0, diagPass2 = 0, diagNW = 0, diagTotal = 0;
+#endif
+    // ROI -> LDS for cells whose source rows are 4-byte aligned: ROI column c lands on byte c + 1 of
+    // its LDS row, so word wd of a row is the source bytes from xa + 4 * (wd - 1) + so + 3 on, taken
+    // from two aligned source words.  A lane copies word wd of row lw of every group of rowsW rows.
+    // issue() requests the first 8 groups into registers (one memory round trip for an ordinary
+    // cell); land() shifts them into LDS and fetches what is left of a very tall cell directly.
+    auto aligned = [&](const FastCell& C) { return (C.w[0] & 255u) > 0u || img0Aligned != 0; };
+    auto source = [&](const FastCell& C, int* pitch) {
+        const u32 t = (C.w[0] >> 24) + 3u;
+        const u8* sbase;
+        if ((C.w[0] & 255u) > 0u) {
+            *pitch = (int)C.w[9];
+            sbase = pyr + (i64)f * g.pyrFrameBytes + C.w[8];
+        } else {
+            *pitch = img0.pitch;
+            sbase = img0.base + (i64)f * img0.frameStride + (i64)(C.w[1] >> 16) * img0.pitch + ((C.w[1] & 0xffff) & ~3u);
+        }
+        // the first source word of LDS word 0 may lie one word before the aligned ROI start: that
+        // signed constant goes into the uniform base, so the 32-bit lane offsets never go negative
+        return sbase + 4 * ((int)(t >> 2) - 1);
+    };
+    auto issue = [&](const FastCell& C, FastPair (&v)[8]) {
+        const int rh = (C.w[0] >> 16) & 255;
+        const int nWc = (int)(C.w[7] & 255), rowsW = (int)((C.w[7] >> 8) & 255);
+        const int lw = (int)fastdiv((u32)lane, (u32)nWc, C.w[5]), wd = lane - lw * nWc;
         if (lw < rowsW) {
-            const u8* sp = im.base + (i64)f * im.frameStride + (i64)(iniY + lw) * im.pitch + xa + 4 * wd;
-            u8* dp = roi + lw * RP + 4 * wd;
-            const int sStep = rowsW * im.pitch, dStep = rowsW * RP;
-#pragma unroll 4
-            for (int y = lw; y < rh; y += rowsW) {
-                *(u32*)dp = *(const u32*)sp;
-                sp += sStep;
-                dp += dStep;
+            int pitch;
+            const u8* sbase = source(C, &pitch);
+            u32 soff = mul24((u32)lw, (u32)pitch) + 4u * (u32)wd;
+            const u32 sStep = (u32)(rowsW * pitch);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (lw + k * rowsW < rh) v[k] = *(const FastPair*)(sbase + soff);
+                soff += sStep;
             }
         }
-    } else {
-        const u32 mg = div_magic(rw);
-        nk = ((3 + iw - 1) >> 2) + 1;
-        rowsPer = 64 / nk;
-        mgk = div_magic(nk);
-        const u8* srow = im.base + (i64)f * im.frameStride + (i64)iniY * im.pitch + iniX;
-        for (int i = lane; i < rw * rh; i += 64) {
-            const int y = fastdiv(i, rw, mg), x = i - y * rw;
-            roi[y * RP + x] = srow[mul24((u32)y, (u32)im.pitch) + x];
-        }
-    }
-    const int X0 = xo + 3, k0 = X0 >> 2;  // interior pixel x sits at byte X0 + x of its ROI row
-    const u8* R = roi + xo;
-    const int nPlaneWords = (pw * (ih + 2) + 3) >> 2;
-    for (int i = lane; i < nPlaneWords; i += 64) ((u32*)plane)[i] = 0;
-    __syncthreads();
-
-    u32* out = slots + (i64)f * g.totalSlots + C.w[2];
-    const int gx0 = C.w[4] & 0xffff, gy0 = C.w[4] >> 16;  // relative to the detection origin
-    // Pair test: a lane owns word kk of row lr inside a group of rowsPer rows and moves down the
-    // interior one group per step, so its addresses advance by a constant and its mask of
-    // pixels that lie inside the interior is fixed.
-    const int lr = (int)fastdiv((u32)lane, (u32)nk, mgk), kk = lane - lr * nk;
-    const bool laneOn = lr < rowsPer;
-    const int xb0 = 4 * (k0 + kk) - X0;  // interior x of the word's first pixel
-    const u32 vmask = (15u << max(-xb0, 0)) & (15u >> (4 - min(max(iw - xb0, 0), 4)));
-    const u8* rcBase = roi + (lr + 3) * RP + 4 * (k0 + kk);
-    const int entBase = (lr << 8) + xb0;
-    int total = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        const int th = min(max(pass == 0 ? iniTh : minTh, 0), 255);
-        const u32 th2 = (u32)th | ((u32)th << 16);
-        if (pass == 1) {
-            for (int i = lane; i < nPlaneWords; i += 64) ((u32*)plane)[i] = 0;
-            __syncthreads();
-        }
-        int n1 = 0;
-        for (int yb = 0; yb < ih; yb += rowsPer) {
-            u32 m4 = 0;
-            if (laneOn && yb + lr < ih) {
-                const u32* rc = (const u32*)(rcBase + yb * RP);
-                const u32 Cw = rc[0], Lw = rc[-1], Rw = rc[1];
-                const u32 Uw = *(const u32*)((const u8*)rc - 3 * RP), Dw = *(const u32*)((const u8*)rc + 3 * RP);
-                const u32 Rt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);  // pixels x + 3
-                const u32 Lf = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels x - 3
-                const u32 M = 0x00FF00FFu;
-                const u32 e = pair_test2(Cw & M, Uw & M, Dw & M, Lf & M, Rt & M, th2);
-                const u32 o = pair_test2(odd_bytes(Cw), odd_bytes(Uw), odd_bytes(Dw), odd_bytes(Lf), odd_bytes(Rt), th2);
-                const u32 mm = (e >> 1) | o;  // bits 14, 15, 30, 31 = pixels 0, 1, 2, 3 of the word
-                m4 = (((mm >> 14) & 3u) | ((mm >> 28) & 12u)) & vmask;
+    };
+    auto land = [&](const FastCell& C, const FastPair (&v)[8]) {
+        const int rh = (C.w[0] >> 16) & 255;
+        const u32 sh = ((C.w[0] >> 24) + 3u) & 3u;
+        const int nWc = (int)(C.w[7] & 255), rowsW = (int)((C.w[7] >> 8) & 255);
+        const int lw = (int)fastdiv((u32)lane, (u32)nWc, C.w[5]), wd = lane - lw * nWc;
+        if (lw < rowsW) {
+            u32 doff = mul24((u32)lw, (u32)RP) + 4u * (u32)wd;
+            const u32 dStep = (u32)(rowsW * RP);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (lw + k * rowsW < rh) *(u32*)(roi + doff) = __builtin_amdgcn_alignbyte(v[k].b, v[k].a, sh);
+                doff += dStep;
             }
-            // ordered compaction: lanes are in raster order and so are the pixels of a word
-            const int c = __popc(m4);
-            const int inc = wave_incl_scan_dpp(c);
-            const int tot = __builtin_amdgcn_readlane(inc, 63);
-            const int ent = entBase + (yb << 8);  // + pixel index in the word = (y << 8 | x) for valid pixels
-            u16* qp = queue + n1 + inc - c;
-            if (m4 & 1u) *qp++ = (u16)ent;
-            if (m4 & 2u) *qp++ = (u16)(ent + 1);
-            if (m4 & 4u) *qp++ = (u16)(ent + 2);
-            if (m4 & 8u) *qp = (u16)(ent + 3);
-            n1 += tot;
-        }
-        __syncthreads();
-        int n2 = 0;
-        for (int base = 0; base < n1; base += 64) {
-            const int wi = base + lane;
-            bool corner = false;
-            u32 ent = 0;
-            if (wi < n1) {
-                ent = queue[wi];
-                const int y = ent >> 8, x = ent & 255;
-                const u8* p = R + (y + 3) * RP + x + 3;
-                const int v = p[0];
-                int d[16];
-                d[0] = v - p[3 * RP];
-                d[1] = v - p[3 * RP + 1];
-                d[2] = v - p[2 * RP + 2];
-                d[3] = v - p[RP + 3];
-                d[4] = v - p[3];
-                d[5] = v - p[-RP + 3];
-                d[6] = v - p[-2 * RP + 2];
-                d[7] = v - p[-3 * RP + 1];
-                d[8] = v - p[-3 * RP];
-                d[9] = v - p[-3 * RP - 1];
-                d[10] = v - p[-2 * RP - 2];
-                d[11] = v - p[-RP - 3];
-                d[12] = v - p[-3];
-                d[13] = v - p[RP - 3];
-                d[14] = v - p[2 * RP - 2];
-                d[15] = v - p[3 * RP - 1];
-                const int m = fast_strength(d);
-                if (m > th) {
-                    corner = true;
-                    plane[(y + 1) * pw + x + 1] = (u8)m;
+            if (8 * rowsW < rh) {  // wave-uniform: cells taller than 8 groups
+                int pitch;
+                const u8* sbase = source(C, &pitch);
+                u32 soff = mul24((u32)(lw + 8 * rowsW), (u32)pitch) + 4u * (u32)wd;
+                const u32 sStep = (u32)(rowsW * pitch);
+                for (int y = lw + 8 * rowsW; y < rh; y += rowsW) {
+                    const FastPair w = *(const FastPair*)(sbase + soff);
+                    *(u32*)(roi + doff) = __builtin_amdgcn_alignbyte(w.b, w.a, sh);
+                    soff += sStep;
+                    doff += dStep;
                 }
             }
-            int tot;
-            const int off = wave_excl_count(corner, &tot);
-            __syncthreads();  // every lane has read its queue entry before the in-place compaction writes
-            if (corner) queue[n2 + off] = (u16)ent;
-            n2 += tot;
+        }
+    };
+
+    FastCell C = cells[min(cell0, g.totalCells - 1)];
+    FastPair pre[8];
+    if (aligned(C)) issue(C, pre);
+    for (int ci = 0; ci < FAST_CPW; ci++) {
+        const int cell = cell0 + ci;
+        if (cell >= g.totalCells) break;
+        const int rw = (C.w[0] >> 8) & 255, rh = (C.w[0] >> 16) & 255;
+        const int cellCap = C.w[3] & 0xffff;
+        u32* cnt = cellCount + (i64)f * g.totalCells + cell;
+        const bool empty = rw < 7 || rh < 7;
+        const int iw = rw - 6, ih = rh - 6;
+        const int nk = (int)((C.w[3] >> 16) & 255), rowsPer = (int)(C.w[3] >> 24);
+        __syncthreads();  // the previous cell's phases are through with the LDS
+        if (!empty) {
+            if (aligned(C)) {
+                land(C, pre);
+            } else {
+                const u32 mg = C.w[10];
+                const int iniX = C.w[1] & 0xffff, iniY = C.w[1] >> 16;
+                const u8* srow = img0.base + (i64)f * img0.frameStride + (i64)iniY * img0.pitch + iniX;
+                for (int i = lane; i < rw * rh; i += 64) {
+                    const int y = fastdiv(i, rw, mg), x = i - y * rw;
+                    roi[y * RP + 1 + x] = srow[mul24((u32)y, (u32)img0.pitch) + x];
+                }
+            }
         }
         __syncthreads();
-        // every plane entry is either 0 or a strength above th, so the response of a
-        // neighbour is simply max(strength - 1, 0)
-        for (int base = 0; base < n2; base += 64) {
-            const int wi = base + lane;
-            bool keep = false;
-            int x = 0, y = 0, s = 0;
-            if (wi < n2) {
-                const u32 ent = queue[wi];
-                y = ent >> 8;
-                x = ent & 255;
-                const u8* q = &plane[(y + 1) * pw + x + 1];
-                s = (int)q[0] - 1;
-#define SC(o) max((int)q[o] - 1, 0)
-                keep = s > SC(-1) && s > SC(1) && s > SC(-pw - 1) && s > SC(-pw) && s > SC(-pw + 1) &&
-                       s > SC(pw - 1) && s > SC(pw) && s > SC(pw + 1);
-#undef SC
-            }
-            int tot;
-            const int off = wave_excl_count(keep, &tot);
-            if (keep && total + off < cellCap) out[total + off] = ORBX_PACK(gx0 + x, gy0 + y, s);
-            total += tot;
+        // request the next cell's ROI now: it arrives while this cell is worked on
+        const FastCell Cn = cells[min(cell + 1, g.totalCells - 1)];
+        if (ci + 1 < FAST_CPW && cell + 1 < g.totalCells && aligned(Cn)) issue(Cn, pre);
+        FAST_STAMP(0);
+        if (empty) {
+            if (lane == 0) *cnt = 0;
+            C = Cn;
+            continue;
         }
-        if (total > 0) break;
+
+        u32* out = slots + (i64)f * g.totalSlots + C.w[2];
+        const int gx0 = C.w[4] & 0xffff, gy0 = C.w[4] >> 16;  // relative to the detection origin
+        // Pair test: a lane owns interior word kk of row lr inside a group of rowsPer rows and moves
+        // down the interior one group per step, so its addresses advance by a constant and its mask
+        // of pixels that lie inside the interior is fixed.
+        const int lr = (int)fastdiv((u32)lane, (u32)nk, C.w[6]), kk = lane - lr * nk;
+        const bool laneOn = lr < rowsPer;
+        // surviving pixels of a word are flagged in bits 14, 15, 30, 31 (pixels 0, 1, 2, 3)
+        const int nv = min(max(iw - 4 * kk, 0), 4);  // pixels of the word that lie inside the interior
+        const u32 vmAll = (((1u << min(nv, 2)) - 1u) << 14) | (((1u << max(nv - 2, 0)) - 1u) << 30);
+        const u32 vmE = vmAll & 0x40004000u, vmO = vmAll & 0x80008000u;
+        const u32 entBase = mul24((u32)(lr + 3), (u32)RP) + 4u * (u32)(kk + 1);  // byte offset of the lane's word in the ROI
+        const u8* rcBase = roi + entBase;
+        const int stepBytes = rowsPer * RP;
+        // 16-byte units that cover plane rows 2 .. rh-3 (rows 0, 1 and the rows past rh-3 are never read;
+        // the plane block holds fastRoiPitch * (tallest ROI) bytes, rounded up to 16)
+        const int planeLo = (2 * RP) >> 4, planeHi = ((rh - 2) * RP + 15) >> 4;
+        int total = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            const int th = pass == 0 ? iniTh : minTh;  // clamped to [0, 255] by the host
+            // notdark(x) = bit 15 of x + (0x8000 + th - v); bright(x) = bit 15 of x + (0x8000 - th - 1 - v)
+            const u32 k1 = 0x8000u + (u32)th, k2 = 0x8000u - (u32)th - 1u;
+            const u32 K1 = k1 | (k1 << 16), K2 = k2 | (k2 << 16);
+            int nW = 0;
+            {
+                const u8* rp = rcBase;
+                u32 ent = entBase;
+                for (int yb = 0; yb < ih; yb += rowsPer) {
+                    u32 m = 0;
+                    if (laneOn && yb + lr < ih) {
+                        const u32* rc = (const u32*)rp;
+                        const u32 Cw = rc[0], Lw = rc[-1], Rw = rc[1];
+                        const u32 Uw = *(const u32*)((const u8*)rc - 3 * RP), Dw = *(const u32*)((const u8*)rc + 3 * RP);
+                        const u32 Rt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);  // pixels x + 3
+                        const u32 Lf = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels x - 3
+                        const u32 M = 0x00FF00FFu;
+                        u32 pe, po;
+                        {
+                            const u32 c = Cw & M, wd = K1 - c, wb = K2 - c;
+                            const u32 u = Uw & M, d = Dw & M, lf = Lf & M, rt = Rt & M;
+                            const u32 nd = ((u + wd) & (d + wd)) | ((lf + wd) & (rt + wd));
+                            const u32 br = ((u + wb) | (d + wb)) & ((lf + wb) | (rt + wb));
+                            pe = ~nd | br;
+                        }
+                        {
+                            const u32 c = (Cw >> 8) & M, wd = K1 - c, wb = K2 - c;
+                            const u32 u = (Uw >> 8) & M, d = (Dw >> 8) & M, lf = (Lf >> 8) & M, rt = (Rt >> 8) & M;
+                            const u32 nd = ((u + wd) & (d + wd)) | ((lf + wd) & (rt + wd));
+                            const u32 br = ((u + wb) | (d + wb)) & ((lf + wb) | (rt + wb));
+                            po = ~nd | br;
+                        }
+                        m = ((pe >> 1) & vmE) | (po & vmO);
+                    }
+                    int tot;
+                    const int off = wave_excl_count(m != 0, &tot);
+                    if (m != 0) wq[nW + off] = m | ent;
+                    nW += tot;
+                    rp += stepBytes;
+                    ent += (u32)stepBytes;
+                }
+            }
+            __syncthreads();
+            FAST_STAMP(1);
+            // word queue -> pixel queue, still raster order
+            int n1 = 0;
+            for (int base = 0; base < nW; base += 64) {
+                const int wi = base + lane;
+                const u32 w = wi < nW ? wq[wi] : 0u;
+                const int c = __popc(w & 0xC000C000u);
+                const int inc = wave_incl_scan_dpp(c);
+                const int tot = __builtin_amdgcn_readlane(inc, 63);
+                const u32 o = w & 0x3FFFu;
+                u16* qp = queue + n1 + inc - c;
+                if (w & 0x4000u) *qp++ = (u16)o;
+                if (w & 0x8000u) *qp++ = (u16)(o + 1);
+                if (w & 0x40000000u) *qp++ = (u16)(o + 2);
+                if (w & 0x80000000u) *qp = (u16)(o + 3);
+                n1 += tot;
+            }
+            __syncthreads();
+            for (int i = planeLo + lane; i < planeHi; i += 64) ((uint4*)plane)[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+            // strength: lanes take queue entries base + lane (low halves) and base + 64 + lane (high halves)
+            int n2 = 0;
+            const u32 safe = (u32)(3 * RP + 4);  // interior pixel (0, 0): its ring stays inside the ROI
+            for (int base = 0; base < n1; base += 128) {
+                const int ia = base + lane, ib = base + 64 + lane;
+                const bool okA = ia < n1, okB = ib < n1;
+                const u32 oa = okA ? (u32)queue[ia] : safe, ob = okB ? (u32)queue[ib] : safe;
+                const u8* pa = roi + oa;
+                const u8* pb = roi + ob;
+#define RING2(dx, dy) ((u32)pa[(dy)*RP + (dx)] | ((u32)pb[(dy)*RP + (dx)] << 16))
+                // D[k] = v - ring[k] + 0x500 in each half (0x401 .. 0x5FF)
+                const u32 V = RING2(0, 0) + 0x05000500u;
+                u32 D[16];
+                D[0] = V - RING2(0, 3);
+                D[1] = V - RING2(1, 3);
+                D[2] = V - RING2(2, 2);
+                D[3] = V - RING2(3, 1);
+                D[4] = V - RING2(3, 0);
+                D[5] = V - RING2(3, -1);
+                D[6] = V - RING2(2, -2);
+                D[7] = V - RING2(1, -3);
+                D[8] = V - RING2(0, -3);
+                D[9] = V - RING2(-1, -3);
+                D[10] = V - RING2(-2, -2);
+                D[11] = V - RING2(-3, -1);
+                D[12] = V - RING2(-3, 0);
+                D[13] = V - RING2(-3, 1);
+                D[14] = V - RING2(-2, 2);
+                D[15] = V - RING2(-1, 3);
+#undef RING2
+                u32 mn3[16], mx3[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    mn3[k] = pk_min3h(D[k], D[(k + 1) & 15], D[(k + 2) & 15]);
+                    mx3[k] = pk_max3h(D[k], D[(k + 1) & 15], D[(k + 2) & 15]);
+                }
+                u32 mn9[16], mx9[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    mn9[k] = pk_min3h(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+                    mx9[k] = pk_max3h(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
+                }
+                // dark = max over arcs of the arc minimum; bright_neg = min over arcs of the arc maximum
+                u32 dk = pk_max3h(mn9[0], mn9[1], mn9[2]), bn = pk_min3h(mx9[0], mx9[1], mx9[2]);
+#pragma unroll
+                for (int k = 3; k < 15; k += 2) {
+                    dk = pk_max3h(dk, mn9[k], mn9[k + 1]);
+                    bn = pk_min3h(bn, mx9[k], mx9[k + 1]);
+                }
+                dk = pk_max3h(dk, mn9[15], mn9[15]);
+                bn = pk_min3h(bn, mx9[15], mx9[15]);
+                // strength = max(dark - 0x500, 0x500 - bright_neg) in each half
+                const i16x2 K = (i16x2)(0x500);
+                i16x2 dkv, bnv;
+                __builtin_memcpy(&dkv, &dk, 4);
+                __builtin_memcpy(&bnv, &bn, 4);
+                const i16x2 st = __builtin_elementwise_max((i16x2)(dkv - K), (i16x2)(K - bnv));
+                const int ma = (int)st.x, mb = (int)st.y;
+                const bool ca = okA && ma > th, cb = okB && mb > th;
+                if (ca) plane[oa] = (u8)ma;
+                if (cb) plane[ob] = (u8)mb;
+                int ta, tb;
+                const int offA = wave_excl_count(ca, &ta);
+                const int offB = wave_excl_count(cb, &tb);
+                __syncthreads();  // every lane has read its queue entries before the in-place compaction writes
+                if (ca) queue[n2 + offA] = (u16)oa;
+                if (cb) queue[n2 + ta + offB] = (u16)ob;
+                n2 += ta + tb;
+            }
+            __syncthreads();
+            FAST_STAMP(2);
+#ifdef ORBX_FAST_DIAG
+            diagN1 += n1;
+            diagN2 += n2;
+            diagPass2 += pass;
+            diagNW += nW;
+#endif
+            // Non-max suppression.  Every plane entry is either 0 or a strength above th, so a pixel of
+            // strength m (response m - 1) beats a neighbour of strength q iff m - 1 > max(q - 1, 0),
+            // i.e. m > max(q, 1): one maximum over the 8 neighbours.
+            for (int base = 0; base < n2; base += 64) {
+                const int wi = base + lane;
+                bool keep = false;
+                u32 o = safe;
+                int s = 0;
+                if (wi < n2) {
+                    o = queue[wi];
+                    const u8* q = plane + o;
+                    const u8* qu = q - RP;
+                    const u8* qd = q + RP;
+                    const int m = q[0];
+                    const int nb = max(max(max((int)q[-1], (int)q[1]), max((int)qu[-1], (int)qu[0])),
+                                       max(max((int)qu[1], (int)qd[-1]), max((int)qd[0], (int)qd[1])));
+                    keep = m > max(nb, 1);
+                    s = m - 1;
+                }
+                int tot;
+                const int off = wave_excl_count(keep, &tot);
+                if (keep && total + off < cellCap) {
+                    const int yy = (int)__umulhi(o, g.fastRoiMagic), xx = (int)o - yy * RP;  // ROI row, byte in row
+                    out[total + off] = ORBX_PACK(gx0 + xx - 4, gy0 + yy - 3, s);
+                }
+                total += tot;
+            }
+            FAST_STAMP(3);
+            if (total > 0) break;
+        }
+        if (lane == 0) *cnt = (u32)min(total, cellCap);
+#ifdef ORBX_FAST_DIAG
+        diagTotal += total;
+#endif
+        C = Cn;
     }
-    if (lane == 0) *cnt = (u32)min(total, cellCap);
+#ifdef ORBX_FAST_DIAG
+    FAST_STAMP(4);
+    if (lane == 0 && d_fastDiag) {
+        unsigned long long* r = d_fastDiag + ((size_t)f * gridDim.y + blockIdx.y) * 8;
+        for (int i = 0; i < 5; i++) r[i] = diagT[i];
+        r[5] = (unsigned long long)(u32)diagN1 | ((unsigned long long)(u32)diagN2 << 32);
+        r[6] = (unsigned long long)(u32)diagTotal | ((unsigned long long)(u32)diagPass2 << 32);
+        r[7] = (unsigned long long)(u32)diagNW;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ quadtree
@@ -1742,10 +1897,14 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
                 mw = std::max(mw, g.lv[l].wCell);
                 mh = std::max(mh, g.lv[l].hCell);
             }
-        g.fastRoiPitch = align_up(mw + 6 + 3, 4);
+        // ROI rows: one word before the interior, ceil(mw / 4) interior words, one after; the
+        // strength plane has the ROI's geometry (and holds the word queue before it is cleared);
+        // the pixel queue has one 16-bit entry per interior pixel
+        g.fastRoiPitch = 4 * ((mw + 3) / 4 + 2);
+        g.fastRoiMagic = div_magic((u32)g.fastRoiPitch);
         g.fastPlaneOff = align_up(g.fastRoiPitch * (mh + 6), 16);
-        g.fastQueueOff = g.fastPlaneOff + align_up((mw + 2) * (mh + 2) + 4, 16);
-        g.fastLdsBytes = g.fastQueueOff + align_up(2 * mw * mh, 16);
+        g.fastQueueOff = g.fastPlaneOff + align_up(g.fastRoiPitch * (mh + 6), 16);
+        g.fastLdsBytes = g.fastQueueOff + align_up(2 * mw * mh + 8, 16);
     }
     g.pyrFrameBytes = align_up((int)std::max<i64>(pyrOff, 64), 256);
     g.blurFrameBytes = align_up((int)blurOff, 256);
@@ -1875,19 +2034,26 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
             const int iniX = MIN_BORDER + cj * L.wCell, iniY = MIN_BORDER + ci * L.hCell;
             const int rw = std::max(std::min(iniX + L.wCell + 6, maxBX) - iniX, 0);
             const int rh = std::max(std::min(iniY + L.hCell + 6, maxBY) - iniY, 0);
-            const int xo = iniX & 3, X0 = xo + 3, iw = std::max(rw - 6, 1);
-            const int nW = (xo + rw + 3) >> 2;
-            const int nk = ((X0 + iw - 1) >> 2) - (X0 >> 2) + 1;
+            const int iw = std::max(rw - 6, 1);
+            const int nk = (iw + 3) / 4, nWc = nk + 2;
             auto magic = [](int d) { return d <= 1 ? 0u : (u32)(0x100000000ull / (u32)d) + 1u; };
             FastCell& F = cells[(size_t)L.cellBase + c];
-            F.w[0] = (u32)l | ((u32)rw << 8) | ((u32)rh << 16);
+            F.w[0] = (u32)l | ((u32)rw << 8) | ((u32)rh << 16) | ((u32)(iniX & 3) << 24);
             F.w[1] = (u32)iniX | ((u32)iniY << 16);
             F.w[2] = (u32)(L.slotBase + c * L.cellCap);
             F.w[3] = (u32)L.cellCap | ((u32)nk << 16) | ((u32)(64 / nk) << 24);
             F.w[4] = (u32)(cj * L.wCell + 3) | ((u32)(ci * L.hCell + 3) << 16);
-            F.w[5] = magic(nW);
+            F.w[5] = magic(nWc);
             F.w[6] = magic(nk);
-            F.w[7] = (u32)nW | ((u32)(64 / std::max(nW, 1)) << 8);
+            F.w[7] = (u32)nWc | ((u32)(64 / nWc) << 8);
+            F.w[8] = l > 0 ? (u32)(L.pyrOff + (i64)iniY * L.pyrPitch + (iniX & ~3)) : 0u;
+            F.w[9] = (u32)L.pyrPitch;
+            F.w[10] = magic(rw);
+            F.w[11] = 0;
+            if (l > 0 && L.pyrOff + (i64)L.pyrPitch * L.h > 0xFFFFFFFFll) {
+                orbx_set_error("internal: pyramid block exceeds 4 GiB");
+                return ORBX_ERR_UNSUPPORTED;
+            }
             if (L.cellCap > 0xffff || rw > 255 || rh > 255) {
                 orbx_set_error("internal: cell record overflow");
                 return ORBX_ERR_UNSUPPORTED;
@@ -2079,9 +2245,10 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     {
         StageTimer t(h, ORBX_STAGE_FAST);
         const int aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0;
-        dim3 grid(n, g.totalCells, 1), block(64, 1, 1);
+        dim3 grid(n, (g.totalCells + FAST_CPW - 1) / FAST_CPW, 1), block(64, 1, 1);
         hipLaunchKernelGGL(k_fast, grid, block, g.fastLdsBytes, st, g, img0, aligned0, (const u8*)h->dPyr,
-                           (const FastCell*)h->dCells, h->dCellCount, h->dSlots, h->cfg.ini_th_fast, h->cfg.min_th_fast);
+                           (const FastCell*)h->dCells, h->dCellCount, h->dSlots, std::min(std::max(h->cfg.ini_th_fast, 0), 255),
+                           std::min(std::max(h->cfg.min_th_fast, 0), 255));
     }
     {
         StageTimer t(h, ORBX_STAGE_QUADTREE);
@@ -2583,5 +2750,15 @@ int orbx_debug_selected(orbx_handle* h, int frame, int level, int* xs, int* ys, 
     *n = cnt;
     return ORBX_OK;
 }
+
+#ifdef ORBX_FAST_DIAG
+// Diagnostic build only: points the k_fast phase records at a caller's device buffer of
+// 8 * frames * cells 64-bit words (NULL turns them off).
+int orbx_debug_fast_diag(unsigned long long* dev_buf) {
+    ORBX_HIP_CHECK(hipDeviceSynchronize());
+    ORBX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_fastDiag), &dev_buf, sizeof(dev_buf)));
+    return ORBX_OK;
+}
+#endif
 
 }  // extern "C"

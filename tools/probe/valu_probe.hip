@@ -54,6 +54,42 @@ __global__ __launch_bounds__(256) void k_op(unsigned* out, int iters, unsigned s
             if (OP == 34) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(v[i]));
             if (OP == 35) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
             if (OP == 36) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(v[i]));
+            if (OP == 37) asm volatile("v_or_b32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 38) asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 39) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 40) asm volatile("v_min3_f32 %0, %0, %1, %0" : "+v"(v[i]) : "v"(c));
+            if (OP == 41) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 42) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 43) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 44) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 45) asm volatile("v_pk_fma_f16 %0, %0, %1, %0" : "+v"(v[i]) : "v"(c));
+            if (OP == 46) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %0" : "+v"(v[i]) : "v"(c));
+            if (OP == 47) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %0" : "+v"(v[i]) : "v"(c));
+            if (OP == 48) asm volatile("v_max_f16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 49) asm volatile("v_max_u16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 50) asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 51) asm volatile("v_bitop3_b32 %0, %0, %1, %0 bitop3:0xc8" : "+v"(v[i]) : "v"(c));
+            if (OP == 52) asm volatile("v_mov_b32 %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 53) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 54) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 55) asm volatile("v_add_u16 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 56) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(v[i]));
+            if (OP == 57) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(v[i]) : "v"(c));
+            if (OP == 58) asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[i]));
+            if (OP == 59) asm volatile("v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(v[i]) : "v"(c));
+            if (OP == 60) asm volatile("v_min_u16_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2" : "+v"(v[i]) : "v"(c));
+            if (OP == 61) asm volatile("v_add_f32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "+v"(v[i]) : "v"(c));
+            if (OP == 62) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(v[i]));
+            if (OP == 63) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 64) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 65) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(unsigned long long*)&v[i & ~1]) : "v"(*(unsigned long long*)&v[(i & ~1)]));
+            if (OP == 66) asm volatile("v_med3_f32 %0, %0, %1, %0" : "+v"(v[i]) : "v"(c));
+            if (OP == 67) asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(v[i]) : "v"(c) : "vcc");
+            if (OP == 68) asm volatile("v_subrev_u32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 69) asm volatile("v_xnor_b32 %0, %0, %1" : "+v"(v[i]) : "v"(c));
+            if (OP == 70) asm volatile("v_add_u32 %0, %1, %0" : "+v"(v[i]) : "s"(c));
+            if (OP == 71) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(v[i]));
+            if (OP == 72) asm volatile("v_and_b32 %0, 15, %0" : "+v"(v[i]));
         }
     }
     unsigned acc = 0;
@@ -124,5 +160,41 @@ int main() {
     run<34>("v_lshlrev_b32", out, ghz);
     run<35>("v_and_b32", out, ghz);
     run<36>("v_cvt_f32_i32", out, ghz);
+    run<37>("v_or_b32", out, ghz);
+    run<38>("v_min_f32", out, ghz);
+    run<39>("v_max_f32", out, ghz);
+    run<40>("v_min3_f32", out, ghz);
+    run<41>("v_pk_min_f16", out, ghz);
+    run<42>("v_pk_max_f16", out, ghz);
+    run<43>("v_pk_add_f16", out, ghz);
+    run<44>("v_pk_mul_f16", out, ghz);
+    run<45>("v_pk_fma_f16", out, ghz);
+    run<46>("v_pk_minimum3_f16", out, ghz);
+    run<47>("v_pk_maximum3_f16", out, ghz);
+    run<48>("v_max_f16", out, ghz);
+    run<49>("v_max_u16", out, ghz);
+    run<50>("v_max_i32", out, ghz);
+    run<51>("v_bitop3_b32", out, ghz);
+    run<52>("v_mov_b32", out, ghz);
+    run<53>("v_pk_sub_i16", out, ghz);
+    run<54>("v_pk_min_u16", out, ghz);
+    run<55>("v_add_u16", out, ghz);
+    run<56>("v_lshrrev_b32", out, ghz);
+    run<57>("v_mbcnt_lo_u32_b32", out, ghz);
+    run<58>("v_add_u32 dpp row_shr", out, ghz);
+    run<59>("v_and_b32 sdwa byte1", out, ghz);
+    run<60>("v_min_u16 sdwa bytes", out, ghz);
+    run<61>("v_add_f32 sdwa", out, ghz);
+    run<62>("v_cvt_f32_ubyte1", out, ghz);
+    run<63>("v_sub_f32", out, ghz);
+    run<64>("v_fmac_f32", out, ghz);
+    run<65>("v_pk_add_f32", out, ghz);
+    run<66>("v_med3_f32", out, ghz);
+    run<67>("v_add_co_u32", out, ghz);
+    run<68>("v_subrev_u32", out, ghz);
+    run<69>("v_xnor_b32", out, ghz);
+    run<70>("v_add_u32 (sgpr src)", out, ghz);
+    run<71>("v_add_u32 (literal)", out, ghz);
+    run<72>("v_and_b32 (inline const)", out, ghz);
     return 0;
 }
