@@ -273,10 +273,13 @@ def main():
             NQ = NT = args.knn
             nq_l = NQ // world
             nt0, nt1 = sdist.shard_range(NT, rank, world)
-            g = torch.Generator(device=dev)
-            g.manual_seed(0xD35C + rank)
-            q_l = torch.randint(0, 256, (nq_l, 32), dtype=torch.uint8, device=dev, generator=g)
-            t_l = torch.randint(0, 256, (nt1 - nt0, 32), dtype=torch.uint8, device=dev, generator=g)
+            # BASELINE config 4 data (seed 0xD35C): random train rows, half of the queries planted
+            # near-duplicates (<= 30 flipped bits), exact ties at higher indices; generated once on
+            # the host, every rank takes its slice of queries and its shard of train rows
+            q_h, t_h, _ = synth.synth_knn_workload(NQ, NT, seed=0xD35C)
+            q_l = torch.from_numpy(q_h[rank * nq_l:(rank + 1) * nq_l]).to(dev)
+            t_l = torch.from_numpy(t_h[nt0:nt1]).to(dev)
+            accept = torch.empty(nq_l, dtype=torch.uint8, device=dev)
 
             def local_knn2(q_all, t_loc, off):
                 bi = torch.empty(q_all.shape[0], dtype=torch.int32, device=dev)
@@ -289,22 +292,49 @@ def main():
                 m.knn2_merge_device(a[0], a[1], a[2], b[0], b[1], b[2])
                 return a
 
-            sdist.knn2_sharded(q_l, t_l, nt0, local_knn2, merge)  # warm-up
-            barrier()
-            t1 = time.perf_counter()
-            reps = 2
-            for _ in range(reps):
-                sdist.knn2_sharded(q_l, t_l, nt0, local_knn2, merge)
-            barrier()
-            dt = time.perf_counter() - t1
+            def search(ql, tl):
+                """One whole job: exchange, local scans, ordered merge, ratio test."""
+                r = sdist.knn2_sharded(ql, tl, nt0, local_knn2, merge)
+                m.ratio_test_device(r[1], r[2], accept)
+                return r
+
+            def time_search(ql, tl, reps=2):
+                search(ql, tl)  # warm-up
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    search(ql, tl)
+                barrier()
+                dt = time.perf_counter() - t1
+                if world > 1:
+                    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt = float(t.item())
+                return float(nq_l * world) * float(NT) * reps / dt
+
+            rate = time_search(q_l, t_l)
+            accepted = int(accept.sum().item())
             if world > 1:
-                t = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt = float(t.item())
-            pairs = float(nq_l * world) * float(NT) * reps
-            int_peak = 256 * 4 * 32 * 2.4e9  # lanes x clock: 32-bit integer ops/s
-            out["hamming"] = {"pairs_per_s": round(pairs / dt, 1), "nq": nq_l * world, "nt": NT,
-                              "int_ops_per_pair": 16, "frac_of_int_valu_peak": round(pairs / dt * 16 / (int_peak * world), 4),
+                ta = torch.tensor([accepted], dtype=torch.int64, device=dev)
+                dist.all_reduce(ta)
+                accepted = int(ta.item())
+            # worst case for the scan's skip of the top-2 update: distances fall along the train rows
+            qa_h, ta_h = synth.synth_knn_adversarial(NQ, NT, seed=0xD35C)
+            rate_adv = time_search(torch.from_numpy(qa_h[rank * nq_l:(rank + 1) * nq_l]).to(dev),
+                                   torch.from_numpy(ta_h[nt0:nt1]).to(dev))
+            # Integer-issue bound of the scan: per pair 8 XOR (2.8 cycles per wave64 instruction per
+            # SIMD, measured) + 8 popcount-accumulate (4.5 cycles), 1024 SIMDs at 2.4 GHz
+            issue_bound = 1024 * 2.4e9 * 64 / (8 * 2.8 + 8 * 4.5)
+            out["hamming"] = {"pairs_per_s": round(rate, 1), "nq": nq_l * world, "nt": NT,
+                              "workload": "seed 0xD35C, 50% planted near-duplicates (<= 30 flips), ties at higher "
+                                          "indices, k=2 + ratio test 0.6 / TH_LOW 50 inside the timed region",
+                              "accepted_matches": accepted,
+                              "pairs_per_s_falling_distances": round(rate_adv, 1),
+                              "int_ops_per_pair": 16,
+                              "issue_bound_pairs_per_s_per_gpu": round(issue_bound, 1),
+                              "frac_of_issue_bound": round(rate / (issue_bound * world), 4),
+                              "issue_bound_note": "8 v_xor at 2.8 + 8 v_bcnt at 4.5 cycles per 64 pairs per SIMD "
+                                                  "(profiles/r1_probes.txt), 1024 SIMDs at 2.4 GHz",
                               "exchange": ("all-gather queries + all-to-all partials (RCCL)" if torch.distributed.get_backend() == "nccl"
                                            else "all-gather queries + all-gather partials (gloo rehearsal)") if world > 1 else "none"}
             m.close()

@@ -430,6 +430,12 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
               int train_index_base, int32_t* best_idx, int32_t* best_d, int32_t* second_d,
               int mem_space);
 
+/* The acceptance rule that follows the best / second-best scan in the reference's descriptor
+ * loops (src/ORBmatcher.cc:284-288, :561-565): accept[i] = best_d[i] <= max_dist (TH_LOW or
+ * TH_HIGH at the call site) && (float)best_d[i] < nn_ratio * (float)second_d[i]. */
+int orbm_ratio_test(orbm_context* m, int nq, const int32_t* best_d, const int32_t* second_d,
+                    float nn_ratio, int max_dist, uint8_t* accept, int mem_space);
+
 /* orbm_knn2 for callers that cannot allocate: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same results as
  * orbm_knn2 with ORBX_MEM_DEVICE (q, t and the three outputs are device arrays, q and t 16-byte

@@ -5,10 +5,21 @@
 //                             that exist in the C ABI)
 //
 // With OpenCV available, define ORBX_WITH_OPENCV before including this header: the
-// classes then take cv::InputArray / std::vector<cv::KeyPoint> / cv::OutputArray exactly
-// like the reference, and Frame.cc / Tracking.cc compile against it unchanged.  Without
-// OpenCV the same classes are expressed on two small stand-in types (orbx::KeyPoint,
-// orbx::Image) so that host code and tests can be built anywhere.
+// extractor then takes cv::InputArray / std::vector<cv::KeyPoint> / cv::OutputArray exactly
+// like the reference.  (That branch needs OpenCV headers; it has not been through a compiler in
+// an image without OpenCV, only the stand-in branch has.)  Without OpenCV the same classes are
+// expressed on two small stand-in types (orbx::KeyPoint, orbx::Image).
+//
+// The matcher offers the reference's own signatures
+//     SearchByProjection(Frame&, const Frame&, th, bMono)              src/ORBmatcher.cc:1533
+//     SearchByProjection(Frame&, const std::vector<MapPoint*>&, th)    :62
+//     SearchForInitialization(Frame&, Frame&, vbPrevMatched, vnMatches12, windowSize)   :501
+//     DescriptorDistance(const Mat&, const Mat&)                       :1905
+// as templates on the Frame / MapPoint / Mat types, so that the call sites of Tracking.cc
+// (:944-950, :1333, :1339, :1943) compile as they stand, against the reference's classes or
+// against any types with the same member names (tests/cpp/ref_standin.hpp).  What a type must
+// offer is listed above each template.  mvImagePyramid is a member of the extractor that
+// fetches a level to the host the first time it is indexed after an extraction.
 //
 // One extractor object owns one orbx handle (one HIP stream).  As in the reference, an
 // object must not be used from two threads at once; two objects may run concurrently
@@ -19,6 +30,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -92,6 +104,7 @@ public:
         keypoints.resize(n);
         if (n) std::memcpy(keypoints.data(), kps_.data(), (size_t)n * sizeof(orbx_keypoint));
         descriptors.assign(desc_.begin(), desc_.begin() + (size_t)n * 32);
+        hostValid_.assign(hostValid_.size(), 0);
     }
 
 #ifdef ORBX_WITH_OPENCV
@@ -103,6 +116,7 @@ public:
         int n = 0;
         orbx::check(orbx_extract(h_, image.data, image.cols, image.rows, image.step, kps_.data(), desc_.data(), cap_, &n),
                     "orbx_extract");
+        hostValid_.assign(hostValid_.size(), 0);
         static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint layout");
         _keypoints.resize(n);
         if (n) std::memcpy((void*)_keypoints.data(), kps_.data(), (size_t)n * sizeof(orbx_keypoint));
@@ -115,6 +129,34 @@ public:
         }
     }
 #endif
+
+    // ---- mvImagePyramid (reference include/ORBextractor.h:73; read by Frame::ComputeStereoMatches,
+    // src/Frame.cc:610, :700, :711, :716).  The levels live in device memory; indexing the member
+    // copies that level to the host once per extraction and hands back a host image (cv::Mat with
+    // OpenCV, orbx::HostImage without): `mvImagePyramid[l].rows`, `.rowRange(..).colRange(..)` and
+    // `mvImagePyramid.size()` read as in the reference.
+#ifdef ORBX_WITH_OPENCV
+    typedef cv::Mat HostLevel;
+#else
+    struct HostLevel {
+        std::vector<unsigned char> pixels;
+        int rows = 0, cols = 0;
+        size_t step = 0;
+        unsigned char* data = nullptr;
+        const unsigned char* ptr(int r) const { return data + (size_t)r * step; }
+        unsigned char at(int r, int c) const { return data[(size_t)r * step + c]; }
+        bool empty() const { return rows == 0 || cols == 0; }
+    };
+#endif
+    class ImagePyramid {
+    public:
+        explicit ImagePyramid(ORBextractor* e) : e_(e) {}
+        size_t size() const { return (size_t)orbx_levels(e_->h_); }
+        const HostLevel& operator[](size_t level) const { return e_->host_level((int)level); }
+    private:
+        ORBextractor* e_;
+    };
+    ImagePyramid mvImagePyramid{this};
 
     int GetLevels() { return orbx_levels(h_); }
     float GetScaleFactor() { return orbx_scale_factor(h_); }
@@ -134,6 +176,35 @@ public:
 
 private:
     std::vector<float> vec(const float* p) { return std::vector<float>(p, p + orbx_levels(h_)); }
+    const HostLevel& host_level(int level) {
+        const int nl = orbx_levels(h_);
+        if (level < 0 || level >= nl) throw std::out_of_range("mvImagePyramid: level out of range");
+        if ((int)hostLevels_.size() != nl) {
+            hostLevels_.assign(nl, HostLevel());
+            hostValid_.assign(nl, 0);
+        }
+        if (!hostValid_[level]) {
+            const uint8_t* p = nullptr;
+            int w = 0, h = 0;
+            orbx::check(orbx_get_level(h_, 0, level, &p, &w, &h, nullptr), "orbx_get_level");
+            HostLevel& L = hostLevels_[level];
+#ifdef ORBX_WITH_OPENCV
+            L.create(h, w, CV_8UC1);
+            orbx::check(orbx_debug_level(h_, 0, level, L.data), "orbx_debug_level");  // tightly packed rows
+#else
+            L.pixels.resize((size_t)w * h);
+            L.rows = h;
+            L.cols = w;
+            L.step = (size_t)w;
+            L.data = L.pixels.data();
+            orbx::check(orbx_debug_level(h_, 0, level, L.data), "orbx_debug_level");
+#endif
+            hostValid_[level] = 1;
+        }
+        return hostLevels_[level];
+    }
+    std::vector<HostLevel> hostLevels_;
+    std::vector<char> hostValid_;
     orbx_handle* h_ = nullptr;
     int cap_ = 0;
     std::vector<orbx_keypoint> kps_;
@@ -179,6 +250,149 @@ public:
     // reference src/ORBmatcher.cc:1905-1921 (descriptor rows of 32 bytes)
     static int DescriptorDistance(const unsigned char* a, const unsigned char* b) { return orbm_hamming256(a, b); }
 
+
+    // ================= the reference's own signatures =================
+    // Requirements on the types (all met by the reference's classes and by cv::):
+    //   Mat:      rows, cols, isContinuous(), template at<T>(r, c), template ptr<T>(r)
+    //   KeyPoint: the 28-byte layout of cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id)
+    //   Frame:    N, mvKeys, mvKeysUn, mvuRight, mDescriptors, mvpMapPoints, mvbOutlier, mTcw, fx, fy, cx,
+    //             cy, mb, mbf, mnMinX, mnMaxX, mnMinY, mnMaxY, mvScaleFactors   (include/Frame.h)
+    //   MapPoint: GetWorldPos(), GetDescriptor(), Observations(), isBad(), mbTrackInView,
+    //             mnTrackScaleLevel, mTrackViewCos, mTrackProjX, mTrackProjY, mTrackProjXR   (include/MapPoint.h)
+
+    // reference src/ORBmatcher.cc:1905-1921: two descriptor rows of 32 bytes
+    template <class MatT>
+    static int DescriptorDistance(const MatT& a, const MatT& b) {
+        return orbm_hamming256(a.template ptr<unsigned char>(0), b.template ptr<unsigned char>(0));
+    }
+
+    // reference src/ORBmatcher.cc:1533-1678.  The pose algebra of :1545-1556 and the projection
+    // of :1570-1578 run here on the host in the reference's order of float operations (a 3x3 by
+    // 3x1 cv::Mat product is the float sum a0*b0 + a1*b1 + a2*b2, left to right; the addition of
+    // the translation rounds once more); the window search, the claims on
+    // CurrentFrame.mvpMapPoints and the rotation histogram run on the GPU.
+    template <class FrameT>
+    int SearchByProjection(FrameT& CurrentFrame, const FrameT& LastFrame, const float th, const bool bMono) {
+        float Rcw[9], tcw[3], Rlw[9], tlw[3];
+        pose(CurrentFrame.mTcw, Rcw, tcw);
+        pose(LastFrame.mTcw, Rlw, tlw);
+        // twc = -Rcw.t() * tcw ; tlc = Rlw * twc + tlw   (:1547, :1551)
+        float twc[3], tlc[3];
+        for (int i = 0; i < 3; i++) twc[i] = -(Rcw[0 + i] * tcw[0] + Rcw[3 + i] * tcw[1] + Rcw[6 + i] * tcw[2]);
+        for (int i = 0; i < 3; i++) tlc[i] = (Rlw[3 * i] * twc[0] + Rlw[3 * i + 1] * twc[1] + Rlw[3 * i + 2] * twc[2]) + tlw[i];
+        const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;
+        const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;
+        const int nLast = LastFrame.N, nCur = CurrentFrame.N;
+        std::vector<unsigned char> valid(nLast, 0), hasObs(nLast, 0), mpDesc((size_t)nLast * 32, 0);
+        std::vector<float> u(nLast, 0.f), v(nLast, 0.f), invz(nLast, 0.f);
+        for (int i = 0; i < nLast; i++) {
+            auto* pMP = LastFrame.mvpMapPoints[i];
+            if (!pMP || LastFrame.mvbOutlier[i]) continue;
+            const auto x3Dw = pMP->GetWorldPos();
+            const float xw = x3Dw.template at<float>(0, 0), yw = x3Dw.template at<float>(1, 0), zw = x3Dw.template at<float>(2, 0);
+            const float xc = (Rcw[0] * xw + Rcw[1] * yw + Rcw[2] * zw) + tcw[0];
+            const float yc = (Rcw[3] * xw + Rcw[4] * yw + Rcw[5] * zw) + tcw[1];
+            const float zc = (Rcw[6] * xw + Rcw[7] * yw + Rcw[8] * zw) + tcw[2];
+            const float invzc = 1.0 / zc;  // a double division rounded to float, as written at :1575
+            valid[i] = 1;
+            invz[i] = invzc;
+            u[i] = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+            v[i] = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+            hasObs[i] = pMP->Observations() > 0 ? 1 : 0;
+            const auto d = pMP->GetDescriptor();
+            std::memcpy(&mpDesc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+        }
+        std::vector<int> claimed;
+        std::vector<unsigned char> claimedObs;
+        claims_in(CurrentFrame, claimed, claimedObs);
+        std::vector<unsigned char> curDesc, lastDesc;
+        orbm_frame c = frame_of(CurrentFrame, curDesc), l = frame_of(LastFrame, lastDesc);
+        int n = 0;
+        orbx::check(orbm_search_by_projection(m_, &c, &l, mpDesc.data(), valid.data(), u.data(), v.data(), invz.data(),
+                                              hasObs.data(), CurrentFrame.mvuRight.data(), CurrentFrame.mvScaleFactors.data(),
+                                              (int)CurrentFrame.mvScaleFactors.size(), CurrentFrame.mbf, th,
+                                              bForward ? 1 : (bBackward ? 2 : 0), mbCheckOrientation, claimed.data(),
+                                              claimedObs.data(), nullptr, &n, ORBX_MEM_HOST),
+                    "orbm_search_by_projection");
+        for (int i2 = 0; i2 < nCur; i2++) {
+            if (claimed[i2] >= kPrior) continue;  // untouched
+            CurrentFrame.mvpMapPoints[i2] = claimed[i2] >= 0 ? LastFrame.mvpMapPoints[claimed[i2]] : nullptr;
+        }
+        return n;
+    }
+
+    // reference src/ORBmatcher.cc:62-155 (Tracking::SearchLocalPoints, src/Tracking.cc:1943)
+    template <class FrameT, class MapPointT>
+    int SearchByProjection(FrameT& F, const std::vector<MapPointT*>& vpMapPoints, const float th = 3) {
+        const int nq = (int)vpMapPoints.size();
+        std::vector<unsigned char> valid(nq, 0), hasObs(nq, 0), desc((size_t)nq * 32, 0);
+        std::vector<float> px(nq, 0.f), py(nq, 0.f), pxr(nq, 0.f), radius(nq, 0.f);
+        std::vector<int> minLevel(nq, 0), maxLevel(nq, 0);
+        const bool bFactor = th != 1.0;
+        for (int i = 0; i < nq; i++) {
+            MapPointT* pMP = vpMapPoints[i];
+            if (!pMP->mbTrackInView) continue;
+            if (pMP->isBad()) continue;
+            const int nPredictedLevel = pMP->mnTrackScaleLevel;
+            float r = pMP->mTrackViewCos > 0.998 ? 2.5 : 4.0;  // RadiusByViewingCos, :158-164
+            if (bFactor) r *= th;
+            valid[i] = 1;
+            px[i] = pMP->mTrackProjX;
+            py[i] = pMP->mTrackProjY;
+            pxr[i] = pMP->mTrackProjXR;
+            radius[i] = r * F.mvScaleFactors[nPredictedLevel];
+            minLevel[i] = nPredictedLevel - 1;
+            maxLevel[i] = nPredictedLevel;
+            hasObs[i] = pMP->Observations() > 0 ? 1 : 0;
+            const auto d = pMP->GetDescriptor();
+            std::memcpy(&desc[(size_t)i * 32], d.template ptr<unsigned char>(0), 32);
+        }
+        orbm_proj_queries q;
+        std::memset(&q, 0, sizeof(q));
+        q.n = nq;
+        q.valid = valid.data();
+        q.u = px.data();
+        q.v = py.data();
+        q.radius = radius.data();
+        q.min_level = minLevel.data();
+        q.max_level = maxLevel.data();
+        q.desc = desc.data();
+        q.has_obs = hasObs.data();
+        q.u_right = pxr.data();
+        q.right_gate = radius.data();
+        const orbm_proj_policy pol = {0, TH_HIGH, 1, mfNNratio, 0};
+        std::vector<int> claimed;
+        std::vector<unsigned char> claimedObs, fDesc;
+        claims_in(F, claimed, claimedObs);
+        orbm_frame f = frame_of(F, fDesc);
+        int n = 0;
+        orbx::check(orbm_search_projected(m_, &f, F.mvuRight.data(), &q, &pol, claimed.data(), claimedObs.data(), nullptr, &n,
+                                          ORBX_MEM_HOST),
+                    "orbm_search_projected");
+        for (int i2 = 0; i2 < F.N; i2++)
+            if (claimed[i2] >= 0 && claimed[i2] < kPrior) F.mvpMapPoints[i2] = vpMapPoints[claimed[i2]];
+        return n;
+    }
+
+    // reference src/ORBmatcher.cc:501-628 (Tracking::MonocularInitialization, src/Tracking.cc:944-950)
+    template <class FrameT, class Point2fT>
+    int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<Point2fT>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                int windowSize = 10) {
+        static_assert(sizeof(Point2fT) == 8, "Point2f must be two floats");
+        const int n1 = (int)F1.mvKeysUn.size();
+        vnMatches12.assign(n1, -1);
+        if (n1 == 0) return 0;
+        std::vector<unsigned char> d1, d2;
+        orbm_frame f1 = frame_of(F1, d1), f2 = frame_of(F2, d2);
+        int n = 0;
+        orbx::check(orbm_search_for_initialization(m_, &f1, &f2, reinterpret_cast<float*>(vbPrevMatched.data()),
+                                                   vnMatches12.data(), windowSize, mfNNratio, mbCheckOrientation, &n,
+                                                   ORBX_MEM_HOST),
+                    "orbm_search_for_initialization");
+        return n;
+    }
+
+    // ================= the same searches on plain arrays =================
     // reference src/ORBmatcher.cc:501-628
     int SearchForInitialization(const FrameView& F1, const FrameView& F2, std::vector<float>& vbPrevMatchedXY,
                                 std::vector<int>& vnMatches12, int windowSize = 10) {
@@ -350,6 +564,49 @@ public:
     orbm_context* context() { return m_; }
 
 protected:
+    // Prior claims (map points a frame's keypoints hold before the call) go in as indices from
+    // kPrior on, so that they can be told from the indices the search assigns.
+    static const int kPrior = 0x40000000;
+    template <class MatT>
+    static void pose(const MatT& Tcw, float* R, float* t) {
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) R[3 * r + c] = Tcw.template at<float>(r, c);
+            t[r] = Tcw.template at<float>(r, 3);
+        }
+    }
+    template <class FrameT>
+    static void claims_in(const FrameT& F, std::vector<int>& claimed, std::vector<unsigned char>& claimedObs) {
+        claimed.assign(F.N, -1);
+        claimedObs.assign(F.N, 0);
+        for (int i = 0; i < F.N; i++)
+            if (F.mvpMapPoints[i]) {
+                claimed[i] = kPrior + i;
+                claimedObs[i] = F.mvpMapPoints[i]->Observations() > 0 ? 1 : 0;
+            }
+    }
+    // mvKeysUn / mDescriptors / image bounds of a Frame as the C ABI's frame (descriptor rows are
+    // copied only when the matrix is not continuous)
+    template <class FrameT>
+    static orbm_frame frame_of(const FrameT& F, std::vector<unsigned char>& scratch) {
+        typedef typename std::remove_reference<decltype(F.mvKeysUn[0])>::type KP;
+        static_assert(sizeof(KP) == sizeof(orbx_keypoint), "keypoints must have the 28-byte cv::KeyPoint layout");
+        orbm_frame f;
+        const int n = (int)F.mvKeysUn.size();
+        f.kps = reinterpret_cast<const orbx_keypoint*>(F.mvKeysUn.data());
+        if (n == 0 || F.mDescriptors.isContinuous()) {
+            f.desc = n ? F.mDescriptors.template ptr<unsigned char>(0) : nullptr;
+        } else {
+            scratch.resize((size_t)n * 32);
+            for (int i = 0; i < n; i++) std::memcpy(&scratch[(size_t)i * 32], F.mDescriptors.template ptr<unsigned char>(i), 32);
+            f.desc = scratch.data();
+        }
+        f.n = n;
+        f.min_x = F.mnMinX;
+        f.min_y = F.mnMinY;
+        f.max_x = F.mnMaxX;
+        f.max_y = F.mnMaxY;
+        return f;
+    }
     static orbm_pyramid pyramid(ORBextractor& e) {
         orbm_pyramid p;
         std::memset(&p, 0, sizeof(p));

@@ -10,6 +10,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "orb_oracle.h"
@@ -338,6 +339,51 @@ int oracle_search_by_projection_frames(const oracle_frame* cur, const oracle_fra
 // reference src/ORBmatcher.cc:62-164: SearchByProjection(Frame&, const vector<MapPoint*>&, th).
 // Per map point: valid = mbTrackInView && !isBad(), the isInFrustum outputs, its descriptor
 // and whether it has observations.  claimed[] plays F.mvpMapPoints.
+// Pose algebra in front of the frame-to-frame search (reference src/ORBmatcher.cc:1545-1556 and
+// :1570-1578): camera motion between the frames decides forward / backward, and every last-frame
+// map point is projected into the current frame.  A cv::Mat product of a 3x3 by a 3x1 float matrix
+// is the float sum a0*b0 + a1*b1 + a2*b2 taken left to right, the added translation rounds once
+// more (OpenCV's small-matrix product; this file is built without contraction).  Tcw / Tlw: 4x4
+// row-major; x3Dw: n x 3.  direction: 0 neither, 1 forward, 2 backward.
+void oracle_project_last_frame(const float* Tcw, const float* Tlw, const float* x3Dw, int n, float fx, float fy, float cx,
+                               float cy, float mb, int bMono, float* u, float* v, float* invz, int* direction) {
+    float Rcw[3][3], tcw[3], Rlw[3][3], tlw[3];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) {
+            Rcw[r][c] = Tcw[4 * r + c];
+            Rlw[r][c] = Tlw[4 * r + c];
+        }
+        tcw[r] = Tcw[4 * r + 3];
+        tlw[r] = Tlw[4 * r + 3];
+    }
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; i++) {  // twc = -Rcw.t()*tcw
+        const float p = Rcw[0][i] * tcw[0] + Rcw[1][i] * tcw[1] + Rcw[2][i] * tcw[2];
+        twc[i] = -p;
+    }
+    for (int i = 0; i < 3; i++) {  // tlc = Rlw*twc + tlw
+        const float p = Rlw[i][0] * twc[0] + Rlw[i][1] * twc[1] + Rlw[i][2] * twc[2];
+        tlc[i] = p + tlw[i];
+    }
+    const bool bForward = tlc[2] > mb && !bMono;
+    const bool bBackward = -tlc[2] > mb && !bMono;
+    *direction = bForward ? 1 : (bBackward ? 2 : 0);
+    for (int k = 0; k < n; k++) {
+        const float* X = x3Dw + 3 * k;
+        float x3Dc[3];
+        for (int i = 0; i < 3; i++) {  // x3Dc = Rcw*x3Dw + tcw
+            const float p = Rcw[i][0] * X[0] + Rcw[i][1] * X[1] + Rcw[i][2] * X[2];
+            x3Dc[i] = p + tcw[i];
+        }
+        const float xc = x3Dc[0];
+        const float yc = x3Dc[1];
+        const float invzc = 1.0 / x3Dc[2];
+        invz[k] = invzc;
+        u[k] = fx * xc * invzc + cx;
+        v[k] = fy * yc * invzc + cy;
+    }
+}
+
 int oracle_search_by_projection_mappoints(const oracle_frame* f, const float* f_u_right, int nmp,
                                           const uint8_t* valid, const float* proj_x, const float* proj_y,
                                           const float* proj_xr, const int* level, const float* view_cos,
@@ -504,6 +550,20 @@ void oracle_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* best_i
         best_d[i] = bestDist1;
         second_d[i] = bestDist2;
     }
+}
+
+// The same scan with the queries split over host threads (every query is still one serial scan).
+void oracle_knn2_mt(const uint8_t* q, int nq, const uint8_t* t, int nt, int* best_idx, int* best_d, int* second_d,
+                    int threads) {
+    threads = std::max(1, std::min(threads, nq));
+    std::vector<std::thread> pool;
+    for (int k = 0; k < threads; k++) {
+        const int i0 = (int)((long long)nq * k / threads), i1 = (int)((long long)nq * (k + 1) / threads);
+        pool.emplace_back([=]() {
+            oracle_knn2(q + (size_t)i0 * 32, i1 - i0, t, nt, best_idx + i0, best_d + i0, second_d + i0);
+        });
+    }
+    for (auto& th : pool) th.join();
 }
 
 // Shared body of the two SearchByBoW overloads (reference src/ORBmatcher.cc:209-355 for

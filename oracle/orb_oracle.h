@@ -130,6 +130,8 @@ int oracle_search_by_projection_frames(const oracle_frame* cur, const oracle_fra
                                        const float* cur_u_right, float bf, float th,
                                        int direction, float nn_ratio, int check_orientation,
                                        int* cur_claimed, uint8_t* cur_claimed_obs, int* query_best);
+void oracle_project_last_frame(const float* Tcw, const float* Tlw, const float* x3Dw, int n, float fx, float fy, float cx,
+                               float cy, float mb, int bMono, float* u, float* v, float* invz, int* direction);
 int oracle_search_by_projection_mappoints(const oracle_frame* f, const float* f_u_right, int nmp,
                                           const uint8_t* valid, const float* proj_x, const float* proj_y,
                                           const float* proj_xr, const int* level, const float* view_cos,
@@ -179,6 +181,8 @@ int oracle_search_by_sim3(const oracle_frame* kf1, const oracle_frame* kf2, cons
  * updates, second-best may equal best, ratio and TH_LOW tests. */
 void oracle_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* best_idx, int* best_d,
                  int* second_d);
+void oracle_knn2_mt(const uint8_t* q, int nq, const uint8_t* t, int nt, int* best_idx, int* best_d,
+                    int* second_d, int threads);
 
 #ifdef __cplusplus
 }

@@ -289,6 +289,19 @@ def search_by_projection_frames(cur, last, valid, u, v, invz, has_obs, u_right, 
     return n, cl[:cur.n].copy(), co[:cur.n].copy()
 
 
+def project_last_frame(Tcw, Tlw, x3dw, fx, fy, cx, cy, mb, mono):
+    """Pose algebra of reference src/ORBmatcher.cc:1545-1556, :1570-1578 -> (u, v, invz, direction)."""
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    Tlw = np.ascontiguousarray(Tlw, np.float32).reshape(16)
+    X = np.ascontiguousarray(x3dw, np.float32).reshape(-1, 3)
+    n = len(X)
+    u, v, iz = (np.zeros(max(n, 1), np.float32) for _ in range(3))
+    d = C.c_int(0)
+    lib().oracle_project_last_frame(_p(Tcw), _p(Tlw), _p(X), n, C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                                    C.c_float(cy), C.c_float(mb), int(bool(mono)), _p(u), _p(v), _p(iz), C.byref(d))
+    return u[:n], v[:n], iz[:n], d.value
+
+
 def search_by_projection_mappoints(f, f_u_right, valid, px, py, pxr, level, view_cos, desc, has_obs, th,
                                    nn_ratio, claimed=None, claimed_obs=None):
     valid = np.ascontiguousarray(valid, np.uint8)
@@ -335,12 +348,15 @@ def search_by_projection_sim3(kf, valid, u, v, level, desc, th, matched=None):
     return n, m[:kf.n].copy()
 
 
-def knn2(q, t):
+def knn2(q, t, threads=1):
     q = np.ascontiguousarray(q, np.uint8)
     t = np.ascontiguousarray(t, np.uint8)
     nq = len(q)
     bi, bd, sd = (np.zeros(nq, np.int32) for _ in range(3))
-    lib().oracle_knn2(_p(q), nq, _p(t), len(t), _p(bi), _p(bd), _p(sd))
+    if threads > 1:
+        lib().oracle_knn2_mt(_p(q), nq, _p(t), len(t), _p(bi), _p(bd), _p(sd), int(threads))
+    else:
+        lib().oracle_knn2(_p(q), nq, _p(t), len(t), _p(bi), _p(bd), _p(sd))
     return bi, bd, sd
 
 

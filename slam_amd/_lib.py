@@ -131,6 +131,7 @@ SIGNATURES = {
                                          C.POINTER(Pyramid), _vp, _vp, _f, _f, _vp, _vp, _vp, _i]),
     "orbm_search_by_projection_batch": (_i, [_vp, C.POINTER(ProjectionPair), _i, _vp, _i, _f, _f, _i]),
     "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
+    "orbm_ratio_test": (_i, [_vp, _i, _vp, _vp, _f, _i, _vp, _i]),
     "orbm_knn2_noalloc": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "orbm_knn2_merge": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
 }

@@ -2128,6 +2128,15 @@ __global__ void k_knn2_merge(int nq, int* ia, int* da, int* sa, const int* ib, c
     sa[i] = s;
 }
 
+// Acceptance rule of the reference's descriptor loops (src/ORBmatcher.cc:284-288): best <= th and
+// (float)best < ratio * (float)second.
+__global__ void k_ratio_test(int nq, const int* __restrict__ bd, const int* __restrict__ sd, float ratio, int th, u8* accept) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int b = bd[i];
+    accept[i] = (b <= th && (float)b < __fmul_rn(ratio, (float)sd[i])) ? 1 : 0;
+}
+
 // The partials of consecutive train slices (slice-major arrays of nq entries) folded in slice order by the same rule.
 __global__ void k_knn2_merge_slices(int nq, int nSlices, const int* pi, const int* pd, const int* ps, int* oi, int* od, int* os) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3637,6 +3646,27 @@ int orbm_knn2_noalloc(orbm_context* m, const uint8_t* q, int nq, const uint8_t* 
     hipLaunchKernelGGL(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, slices, (const int*)pi,
                        (const int*)pd, (const int*)ps, (int*)best_idx, (int*)best_d, (int*)second_d);
     ORBX_HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbm_ratio_test(orbm_context* m, int nq, const int32_t* best_d, const int32_t* second_d, float nn_ratio, int max_dist,
+                    uint8_t* accept, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (nq < 0 || !best_d || !second_d || !accept) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (nq == 0) return ORBX_OK;
+    const int *db, *ds;
+    u8* da;
+    if ((rc = stage_in(m, SL_KNN_D, (const int*)best_d, (size_t)nq, mem_space, &db))) return rc;
+    if ((rc = stage_in(m, SL_KNN_S, (const int*)second_d, (size_t)nq, mem_space, &ds))) return rc;
+    if ((rc = stage_out(m, SL_KNN_I, (u8*)accept, (size_t)nq, mem_space, &da))) return rc;
+    ORBM_LAUNCH(k_ratio_test, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, db, ds, nn_ratio, max_dist, da);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (u8*)accept, (const u8*)da, (size_t)nq, mem_space))) return rc;
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 

@@ -474,6 +474,12 @@ class ORBmatcher:
         s = np.asarray(second_d)
         return (b <= th) & (b.astype(np.float32) < np.float32(self.mfNNratio) * s.astype(np.float32))
 
+    def ratio_test_device(self, best_d, second_d, accept, th=None):
+        """Device form of ratio_test on torch tensors: int32 (nq,), int32 (nq,), uint8 (nq,) out."""
+        check(self._lib.orbm_ratio_test(self._m, best_d.shape[0], best_d.data_ptr(), second_d.data_ptr(),
+                                        float(self.mfNNratio), self.TH_LOW if th is None else th,
+                                        accept.data_ptr(), _lib.MEM_DEVICE))
+
     def set_stream(self, stream_ptr):
         """Run on the hipStream_t with this handle value (0 / None = the legacy default stream)."""
         check(self._lib.orbm_set_stream(self._m, C.c_void_p(stream_ptr or None)))

@@ -103,6 +103,57 @@ def perturb_descriptors(desc, seed, max_flips=30):
     return out
 
 
+def popcount_rows(x):
+    """Number of set bits of each row of an (n, 32) uint8 array."""
+    return np.unpackbits(x, axis=1).sum(axis=1).astype(np.int32)
+
+
+def synth_knn_workload(nq, nt, seed=0xD35C, max_flips=30, dup_every=16):
+    """Brute-force matching workload: nt random train descriptors; every even query is a train
+    row with at most max_flips flipped bits (a planted near-duplicate, so that the ratio test
+    has something to accept), every odd query is random.  Every dup_every-th planted query has
+    its train row repeated at a HIGHER index (an exact tie: the lower index must win and the
+    second-best distance must equal the best).  Returns q, t and a dict: planted (index of the
+    planted row or -1), planted_d (its distance), has_dup (bool)."""
+    t = synth_descriptors(nt, seed)
+    q = synth_descriptors(nq, seed + 1)
+    lo = (3 * nt) // 4
+    n_pl = (nq + 1) // 2
+    r = np.random.RandomState(seed & 0x7FFFFFFF)
+    src = r.permutation(lo)[:n_pl] if n_pl <= lo else r.randint(0, lo, n_pl)
+    planted = np.full(nq, -1, np.int64)
+    planted[0::2] = src[:len(planted[0::2])]
+    has_dup = np.zeros(nq, bool)
+    n_dup = min(len(src) // dup_every, nt - lo)
+    if n_dup > 0:
+        dup_q = np.arange(n_dup) * 2 * dup_every          # planted queries that get a tie
+        dup_rows = lo + r.permutation(nt - lo)[:n_dup]       # distinct rows above every planted row
+        t[dup_rows] = t[planted[dup_q]]
+        has_dup[dup_q] = True
+    pl = np.nonzero(planted >= 0)[0]
+    q[pl] = perturb_descriptors(t[planted[pl]], seed + 2, max_flips)
+    planted_d = np.full(nq, -1, np.int32)
+    planted_d[pl] = popcount_rows(q[pl] ^ t[planted[pl]])
+    return q, t, dict(planted=planted, planted_d=planted_d, has_dup=has_dup)
+
+
+def synth_knn_adversarial(nq, nt, seed=0xD35C):
+    """Worst case for a scan that skips its top-2 update when no distance can improve: train row
+    j differs from a centre descriptor in 256 * (nt - 1 - j) // nt fixed bit positions (nested
+    sets), and every query is the centre with a few flips, so along the scan the distance of
+    every query keeps falling and nearly every row is a new best."""
+    c = synth_descriptors(1, seed + 7)[0]
+    order = np.random.RandomState((seed + 7) & 0x7FFFFFFF).permutation(256)
+    masks = np.zeros((257, 32), np.uint8)
+    for k in range(1, 257):
+        masks[k] = masks[k - 1]
+        masks[k, order[k - 1] >> 3] |= np.uint8(1 << (order[k - 1] & 7))
+    kj = (256 * (nt - 1 - np.arange(nt, dtype=np.int64))) // nt
+    t = c[None, :] ^ masks[kj]
+    q = perturb_descriptors(np.repeat(c[None, :], nq, axis=0), seed + 8, 8)
+    return q, np.ascontiguousarray(t)
+
+
 # ---------------------------------------------------------------- torch twin
 def _t_splitmix64(x):
     """splitmix64 on torch int64 (two's-complement wrap == uint64 arithmetic)."""

@@ -35,6 +35,16 @@ int main(int argc, char** argv) {
         std::fwrite(&n, 4, 1, o);
         std::fwrite(keys.data(), sizeof(orbx::KeyPoint), keys.size(), o);
         std::fwrite(desc.data(), 1, desc.size(), o);
+        {
+            // mvImagePyramid as Frame::ComputeStereoMatches reads it (reference src/Frame.cc:610, :700)
+            ORB_SLAM2::ORBextractor* mpORBextractorLeft = &extractor;
+            const int nRows = mpORBextractorLeft->mvImagePyramid[0].rows;
+            const int lvl = 3;
+            const ORB_SLAM2::ORBextractor::HostLevel& L3 = mpORBextractorLeft->mvImagePyramid[lvl];
+            const int dims[4] = {nRows, (int)mpORBextractorLeft->mvImagePyramid.size(), L3.rows, L3.cols};
+            std::fwrite(dims, 4, 4, o);
+            for (int r = 0; r < L3.rows; r++) std::fwrite(L3.ptr(r), 1, (size_t)L3.cols, o);
+        }
         if (argc == 6) {
             std::vector<unsigned char> imgR((size_t)w * h);
             FILE* fr = std::fopen(argv[5], "rb");
