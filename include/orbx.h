@@ -149,6 +149,11 @@ int orbx_profile_reset(orbx_handle* h);
  * sine/cosine (radians) and fastAtan2 (degrees), n values each, host arrays. */
 int orbx_debug_sincos(orbx_handle* h, const float* angles, int n, float* sin_out, float* cos_out);
 int orbx_debug_atan2(orbx_handle* h, const float* y, const float* x, int n, float* out);
+/* The constant tables of the descriptor kernel as they sit in device memory, 752 words: 248
+ * weight words and 248 membership words of the radius-15 orientation patch (31 rows x 8 words
+ * covering u = -16..15; weight byte = u + 15), then the 256 rBRIEF tests as (x0, y0, x1, y1)
+ * signed bytes (reference src/ORBextractor.cc:135-393, :450-465). */
+int orbx_debug_tables(orbx_handle* h, uint32_t* out, int n);
 /* The taps below number frames as orbx_get_level does: `frame` is the index in the batch of the
  * last call, and only the frames of its last pass are resident (ORBX_ERR_INVALID otherwise).
  * Pyramid level image of frame `frame`: copies w*h bytes, tightly packed, to host dst. */

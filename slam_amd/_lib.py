@@ -93,6 +93,7 @@ SIGNATURES = {
     "orbx_profile_read": (_i, [_vp, _vp, _vp, _i]),
     "orbx_profile_reset": (_i, [_vp]),
     "orbx_debug_sincos": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "orbx_debug_tables": (_i, [_vp, _vp, _i]),
     "orbx_debug_atan2": (_i, [_vp, _vp, _vp, _i, _vp]),
     "orbx_debug_level": (_i, [_vp, _i, _i, _vp]),
     "orbx_debug_blurred": (_i, [_vp, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i)]),

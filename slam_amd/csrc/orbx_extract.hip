@@ -2650,6 +2650,16 @@ int orbx_debug_sincos(orbx_handle* h, const float* angles, int n, float* sin_out
     return ORBX_OK;
 }
 
+int orbx_debug_tables(orbx_handle* h, uint32_t* out, int n) {
+    if (!h || !out || n < 0) return ORBX_ERR_INVALID;
+    DescribeTables t;
+    ORBX_HIP_CHECK(hipSetDevice(h->device));
+    ORBX_HIP_CHECK(hipMemcpyFromSymbol(&t, HIP_SYMBOL(d_tables), sizeof(t)));
+    const u32* w = (const u32*)&t;
+    for (int i = 0; i < n && i < (int)(sizeof(t) / 4); i++) out[i] = w[i];
+    return ORBX_OK;
+}
+
 int orbx_debug_atan2(orbx_handle* h, const float* y, const float* x, int n, float* out) {
     if (!h || n < 0 || !y || !x || !out) return ORBX_ERR_INVALID;
     if (n == 0) return ORBX_OK;

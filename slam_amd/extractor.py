@@ -164,6 +164,11 @@ class ORBextractor:
         check(self._lib.orbx_debug_atan2(self._h, y.ctypes.data, x.ctypes.data, len(y), out.ctypes.data))
         return out
 
+    def debug_tables(self):
+        out = np.zeros(752, np.uint32)
+        check(self._lib.orbx_debug_tables(self._h, out.ctypes.data, len(out)))
+        return out
+
     def debug_blurred(self, frame, level):
         _, w, h, _ = self.level_info(frame, level)
         out = np.zeros((h, w), np.uint8)
