@@ -61,7 +61,16 @@ typedef struct orbx_config {
     int32_t max_height;   /* largest image height */
     int32_t max_batch;    /* frames processed per internal pass (scratch is sized for this) */
     int32_t device;       /* HIP device ordinal */
-    int32_t blur_variant; /* 0: Gaussian taps {18,34,49,55,49,34,18}; 1: {18,34,48,56,48,34,18} */
+    /* Which build of the reference is reproduced where its results depend on the OpenCV version or
+     * on compiler flags.  blur_variant: 0 = Gaussian taps {18,34,49,55,49,34,18} with an integer
+     * column pass (OpenCV 3.4.1 .. 4.4); 1 = taps {18,34,48,56,48,34,18} (OpenCV >= 4.5); 2 = the taps
+     * of 0 with the single-precision column pass of OpenCV <= 3.4.0, the versions the reference's
+     * README names (ties round to even; the last width % 4 columns as in 0).  fma_variant: 0 = the
+     * descriptor's steering sums x*b + y*a, x*a - y*b with every product rounded (a build without
+     * fused multiply-add); 1 = the first product fused into the sum (GCC with -march=native on a
+     * host that has FMA, perfect/CMakeLists.txt:20). */
+    int32_t blur_variant;
+    int32_t fma_variant;
 } orbx_config;
 
 typedef struct orbx_handle orbx_handle;

@@ -177,7 +177,7 @@ inline int reflect101(int i, int n) {
 // Called at reference src/ORBextractor.cc:1094-1095 on a clone of the level.
 void gaussian7(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride,
                int variant) {
-    static const int K257[7] = {18, 34, 49, 55, 49, 34, 18};
+    static const int K257[7] = {18, 34, 49, 55, 49, 34, 18};  // variants 0 and 2
     static const int K256[7] = {18, 34, 48, 56, 48, 34, 18};
     const int* k = variant == 1 ? K256 : K257;
     // row sums fit 16 bits (257 * 255 = 65535)
@@ -201,7 +201,24 @@ void gaussian7(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, s
         uint8_t* D = dst + (size_t)y * dstride;
         const uint16_t* r[7];
         for (int i = -3; i <= 3; i++) r[i + 3] = rows.data() + (size_t)reflect101(y + i, h) * w;
-        for (int x = 0; x < w; x++) {
+        // Variant 2 (OpenCV up to 3.4.0, the versions the reference's README names): the column pass of
+        // the 32-bit row sums runs in SSE2 single precision.  The column taps are the integers scaled by
+        // 2^-16 as floats; per pixel s = (float)S[0]*ky[0], then s += (float)(S[k] + S[-k]) * ky[k] for
+        // k = 1..3, and the result is converted with round-half-to-even (cvtps2dq) and saturated.  The
+        // vector loop covers the columns in fours; the last w % 4 columns take the scalar fixed-point
+        // cast, which rounds half up like variant 0.
+        const int xvec = variant == 2 ? (w & ~3) : 0;
+        const float ky[4] = {(float)k[3] * (1.f / 65536.f), (float)k[2] * (1.f / 65536.f), (float)k[1] * (1.f / 65536.f),
+                             (float)k[0] * (1.f / 65536.f)};
+        for (int x = 0; x < xvec; x++) {
+            float s0 = (float)(int)r[3][x] * ky[0];
+            s0 = s0 + (float)((int)r[4][x] + (int)r[2][x]) * ky[1];
+            s0 = s0 + (float)((int)r[5][x] + (int)r[1][x]) * ky[2];
+            s0 = s0 + (float)((int)r[6][x] + (int)r[0][x]) * ky[3];
+            const int v = (int)lrintf(s0);
+            D[x] = (uint8_t)std::min(std::max(v, 0), 255);
+        }
+        for (int x = xvec; x < w; x++) {
             const int s = k[0] * (r[0][x] + r[6][x]) + k[1] * (r[1][x] + r[5][x]) + k[2] * (r[2][x] + r[4][x]) + k[3] * r[3][x];
             const int v = (s + 32768) >> 16;
             D[x] = (uint8_t)std::min(v, 255);
@@ -558,8 +575,11 @@ float ic_angle(const uint8_t* img, size_t stride, int x, int y, const int* umax)
 // reference src/ORBextractor.cc:91-131.  cos/sin on a float argument under
 // `using namespace std` select the float overloads, i.e. cosf/sinf.
 const float factorPI = (float)(M_PI / 180.f);
+// fma_variant 1: a build of the reference with -march=native on a host with fused multiply-add
+// (perfect/CMakeLists.txt:20) lets GCC contract `x*b + y*a` and `x*a - y*b`: the first product is
+// fused into the addition, the second product is rounded on its own.
 void orb_descriptor(const uint8_t* img, size_t stride, int x, int y, float angle_deg,
-                    uint8_t* desc) {
+                    uint8_t* desc, int fma_variant = 0) {
     float angle = angle_deg * factorPI;
     float a = cosf(angle), b = sinf(angle);
     const uint8_t* center = img + (size_t)y * stride + x;
@@ -567,6 +587,10 @@ void orb_descriptor(const uint8_t* img, size_t stride, int x, int y, float angle
     const signed char* pat = ORBX_PATTERN_31;
     auto get = [&](int idx) -> int {
         float px = (float)pat[2 * idx], py = (float)pat[2 * idx + 1];
+        if (fma_variant == 1) {
+            const float t1 = py * a, t2 = py * b;
+            return center[cv_round(fmaf(px, b, t1)) * step + cv_round(fmaf(px, a, -t2))];
+        }
         return center[cv_round(px * b + py * a) * step + cv_round(px * a - py * b)];
     };
     for (int i = 0; i < 32; ++i, pat += 32) {
@@ -666,7 +690,7 @@ int extract(const oracle_params& p, const Tables& t, const uint8_t* img, int w, 
         lap(4);
         for (size_t i = 0; i < v.size(); i++)
             orb_descriptor(blurred.d.data(), L.w, cv_round(v[i].x), cv_round(v[i].y), v[i].angle,
-                           desc + (size_t)(offset + i) * 32);
+                           desc + (size_t)(offset + i) * 32, p.fma_variant);
         if (level != 0) {
             float scale = t.scale[level];
             for (auto& k : v) {
@@ -771,7 +795,7 @@ int oracle_distribute(const int* xs, const int* ys, const int* resp, int n, int 
 }
 
 float oracle_ic_angle(const uint8_t* lvl, size_t stride, int x, int y) {
-    oracle_params p = {1000, 1.2f, 8, 20, 7, 0};
+    oracle_params p = {1000, 1.2f, 8, 20, 7, 0, 0};
     static const Tables t = make_tables(p);
     return ic_angle(lvl, stride, x, y, t.umax);
 }

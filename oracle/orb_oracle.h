@@ -37,7 +37,9 @@ typedef struct oracle_params {
     int nlevels;
     int ini_th_fast;
     int min_th_fast;
-    int blur_variant; /* 0: integer kernel summing to 257; 1: kernel summing to 256 */
+    int blur_variant; /* 0: integer kernel summing to 257; 1: kernel summing to 256; 2: the 257 kernel with the
+                         single-precision column pass of OpenCV <= 3.4.0 (round half to even) */
+    int fma_variant;  /* 0: x*b + y*a with every product rounded; 1: first product fused into the sum */
 } oracle_params;
 
 /* ---- constructor tables: reference src/ORBextractor.cc:399-466 ---- */

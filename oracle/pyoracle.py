@@ -19,7 +19,8 @@ assert KP_DTYPE.itemsize == 28
 
 class Params(C.Structure):
     _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
-                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("blur_variant", C.c_int)]
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("blur_variant", C.c_int),
+                ("fma_variant", C.c_int)]
 
 
 class Frame(C.Structure):
@@ -52,8 +53,8 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def params(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, blur_variant=0):
-    return Params(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant)
+def params(nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, blur_variant=0, fma_variant=0):
+    return Params(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant, fma_variant)
 
 
 def tables(p):

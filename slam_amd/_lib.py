@@ -26,7 +26,7 @@ class Config(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("max_width", C.c_int32),
                 ("max_height", C.c_int32), ("max_batch", C.c_int32), ("device", C.c_int32),
-                ("blur_variant", C.c_int32)]
+                ("blur_variant", C.c_int32), ("fma_variant", C.c_int32)]
 
 
 class ProjQueries(C.Structure):

@@ -276,7 +276,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // bits (257*255 = 65535); output = sat_u8((sum + 32768) >> 16).
 __global__ __launch_bounds__(256) void k_blur(Geom g, ImgRef img0, const u8* __restrict__ pyr,
                                                u8* __restrict__ blur, int k0, int k1, int k2, int k3,
-                                               int tileOffset) {
+                                               int tileOffset, int halfEven) {
     __shared__ u8 tin[BLUR_TH + 6][BLUR_TW + 8];
     __shared__ u16 hs[BLUR_TH + 6][BLUR_TW];
     const int f = blockIdx.y;
@@ -314,7 +314,10 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, ImgRef img0, const u8* __r
             const int x = rx + k;
             const int s = k0 * ((int)hs[ry][x] + hs[ry + 6][x]) + k1 * ((int)hs[ry + 1][x] + hs[ry + 5][x]) +
                           k2 * ((int)hs[ry + 2][x] + hs[ry + 4][x]) + k3 * (int)hs[ry + 3][x];
-            int v = (s + 32768) >> 16;
+            // halfEven: ties go to the even value in the columns below w & ~3 (single-precision column
+            // pass of OpenCV <= 3.4.0; its last w % 4 columns round half up like the integer path)
+            const int bias = (halfEven && ox + k < (L.w & ~3)) ? 0x7FFF + ((s >> 16) & 1) : 32768;
+            int v = (s + bias) >> 16;
             v = v > 255 ? 255 : v;
             out |= (u32)v << (8 * k);
         }
@@ -330,6 +333,8 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, ImgRef img0, const u8* __r
 // group); reflect-101 at the image's left/right edges is a per-lane byte
 // permutation fixed at start-up, at the top/bottom a reflected row index.
 // The 7 taps of a row are two 4-byte dot products (v_dot4_u32_u8).
+// HALF_EVEN: rounding of the column pass as in k_blur.
+template <bool HALF_EVEN>
 __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const u8* __restrict__ pyr,
                                                       u8* __restrict__ blur, int k0, int k1, int k2, int k3,
                                                       int firstLevel) {
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
     u8* dst = blur + (i64)f * g.blurFrameBytes + L.blurOff + 4 * gx;
     const int gl = max(gx - 1, 0), gr = min(gx + 1, G - 1);
     const bool lastGroup = gx == G - 1;
+    const u32 tailUp = (lastGroup && (w & 3)) ? 1u : 0u;
 
     // byte selectors for the 12 positions x = 4*gx-4 .. 4*gx+7
     u32 selL = 0, selC = 0, selR = 0;
@@ -452,10 +458,11 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
                 const u32 P3 = lastHs[k] | (hs[k] << 16);
                 win[(ph + 6) % 7][k] = P3;
                 lastHs[k] = hs[k];
-                u32 s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 1) % 7][k]), as_u16x2(W01), 32768u, false);
+                u32 s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 1) % 7][k]), as_u16x2(W01), HALF_EVEN ? 0u : 32768u, false);
                 s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 3) % 7][k]), as_u16x2(W23), s, false);
                 s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 5) % 7][k]), as_u16x2(W21), s, false);
                 s = __builtin_amdgcn_udot2(as_u16x2(P3), as_u16x2(W0h), s, false);
+                if (HALF_EVEN) s += 0x7FFFu + (((s >> 16) & 1u) | tailUp);  // ties to even; the image's last w % 4 columns half up
                 sv[k] = min(s, 0xFFFFFFu);
             }
             const u32 lo = __builtin_amdgcn_perm(sv[1], sv[0], 0x0c0c0602u);  // bytes: sv0[2], sv1[2], 0, 0
@@ -1406,6 +1413,10 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 //      copied to LDS with six row-coalesced direct-to-LDS loads and the 512 byte gathers of a
 //      keypoint hit LDS: gathering from global memory costs a wave up to 64 cache-line
 //      lookups per load instruction, which bounded this kernel.
+// FMA = true: the steering sums x*b + y*a and x*a - y*b with the first product fused into the sum
+// (what GCC emits for the reference when it is built for a host with fused multiply-add,
+// perfect/CMakeLists.txt:20); false: every product rounded, as written (src/ORBextractor.cc:103-104).
+template <bool FMA>
 __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8* __restrict__ pyr,
                                                    const u8* __restrict__ blur,
                                                    const u32* __restrict__ sel,
@@ -1587,10 +1598,18 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
             u32 t0[4], t1[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float fr0 = __fadd_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)), 12582912.f);
-                const float fc0 = __fadd_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)), 12582912.f);
-                const float fr1 = __fadd_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)), 12582912.f);
-                const float fc1 = __fadd_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)), 12582912.f);
+                float fr0, fc0, fr1, fc1;
+                if (FMA) {
+                    fr0 = __fadd_rn(__fmaf_rn(px0[r], b, __fmul_rn(py0[r], a)), 12582912.f);
+                    fc0 = __fadd_rn(__fmaf_rn(px0[r], a, -__fmul_rn(py0[r], b)), 12582912.f);
+                    fr1 = __fadd_rn(__fmaf_rn(px1[r], b, __fmul_rn(py1[r], a)), 12582912.f);
+                    fc1 = __fadd_rn(__fmaf_rn(px1[r], a, -__fmul_rn(py1[r], b)), 12582912.f);
+                } else {
+                    fr0 = __fadd_rn(__fadd_rn(__fmul_rn(px0[r], b), __fmul_rn(py0[r], a)), 12582912.f);
+                    fc0 = __fadd_rn(__fsub_rn(__fmul_rn(px0[r], a), __fmul_rn(py0[r], b)), 12582912.f);
+                    fr1 = __fadd_rn(__fadd_rn(__fmul_rn(px1[r], b), __fmul_rn(py1[r], a)), 12582912.f);
+                    fc1 = __fadd_rn(__fsub_rn(__fmul_rn(px1[r], a), __fmul_rn(py1[r], b)), 12582912.f);
+                }
                 const u32 a0 = mad24(__float_as_uint(fr0), 4 * DESC_ROW_DW, __float_as_uint(fc0)) + bc;
                 const u32 a1 = mad24(__float_as_uint(fr1), 4 * DESC_ROW_DW, __float_as_uint(fc1)) + bc;
                 t0[r] = *(const __attribute__((address_space(3))) u8*)(size_t)a0;
@@ -2221,13 +2240,13 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         if (!aligned0) {
             dim3 grid(g.lv[0].blurTiles, n, 1), block(256, 1, 1);
             hipLaunchKernelGGL(k_blur, grid, block, 0, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
-                               h->gaussK[1], h->gaussK[2], h->gaussK[3], 0);
+                               h->gaussK[1], h->gaussK[2], h->gaussK[3], 0, h->cfg.blur_variant == 2 ? 1 : 0);
         }
         for (int l = 1; l < g.nlevels; l++) {
             if (g.lv[l].h >= 4 && g.lv[l].w >= 4) continue;
             dim3 grid(g.lv[l].blurTiles, n, 1), block(256, 1, 1);
             hipLaunchKernelGGL(k_blur, grid, block, 0, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
-                               h->gaussK[1], h->gaussK[2], h->gaussK[3], g.lv[l].blurTileBase);
+                               h->gaussK[1], h->gaussK[2], h->gaussK[3], g.lv[l].blurTileBase, h->cfg.blur_variant == 2 ? 1 : 0);
         }
         const int itemBegin = g.lv[first].blurItemBase;
         if (first < g.nlevels && g.totalBlurItems > itemBegin) {
@@ -2235,7 +2254,8 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             Geom gs = g;
             for (int l = first; l < g.nlevels; l++) gs.lv[l].blurItemBase -= itemBegin;
             dim3 grid(n, (g.totalBlurItems - itemBegin + 255) / 256, 1), block(256, 1, 1);
-            hipLaunchKernelGGL(k_blur_stream, grid, block, 0, bst, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+            auto kb = h->cfg.blur_variant == 2 ? k_blur_stream<true> : k_blur_stream<false>;
+            hipLaunchKernelGGL(kb, grid, block, 0, bst, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
                                h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
         }
     }
@@ -2262,7 +2282,8 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         StageTimer t(h, ORBX_STAGE_DESCRIBE);
         const int nChunks = (std::min(cap, g.totalSel) + 4 * DESC_KPW - 1) / (4 * DESC_KPW);
         dim3 grid(8 * ((n + 7) / 8) * nChunks, 1, 1), block(256, 1, 1);
-        hipLaunchKernelGGL(k_describe, grid, block, 0, st, g, img0, (const u8*)h->dPyr, (const u8*)h->dBlur,
+        auto kd = h->cfg.fma_variant == 1 ? k_describe<true> : k_describe<false>;
+        hipLaunchKernelGGL(kd, grid, block, 0, st, g, img0, (const u8*)h->dPyr, (const u8*)h->dBlur,
                            (const u32*)h->dSel, (const int*)h->dSelCount, dKps, dDesc, cap, dN, h->dErr, n, nChunks,
                            div_magic((u32)nChunks));
     }
@@ -2296,7 +2317,8 @@ int orbx_create(const orbx_config* cfg, orbx_handle** out) {
     }
     *out = nullptr;
     if (cfg->nlevels < 1 || cfg->nlevels > ORBX_MAX_LEVELS || cfg->nfeatures < 1 ||
-        !(cfg->scale_factor > 1.0f) || cfg->max_batch < 1 || cfg->max_width < 1 || cfg->max_height < 1) {
+        !(cfg->scale_factor > 1.0f) || cfg->max_batch < 1 || cfg->max_width < 1 || cfg->max_height < 1 ||
+        cfg->blur_variant < 0 || cfg->blur_variant > 2 || cfg->fma_variant < 0 || cfg->fma_variant > 1) {
         orbx_set_error("invalid configuration");
         return ORBX_ERR_INVALID;
     }

@@ -19,11 +19,11 @@ class ORBextractor:
     FAST_SCORE = 1
 
     def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width=640,
-                 max_height=480, max_batch=1, device=0, blur_variant=0):
+                 max_height=480, max_batch=1, device=0, blur_variant=0, fma_variant=0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         cfg = Config(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width, max_height,
-                     max_batch, device, blur_variant)
+                     max_batch, device, blur_variant, fma_variant)
         self._cfg = cfg
         check(self._lib.orbx_create(C.byref(cfg), C.byref(self._h)))
         self.nlevels = nlevels

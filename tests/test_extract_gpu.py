@@ -474,3 +474,67 @@ def test_debug_taps_number_frames_like_get_level(oracle):
                 tap()
     finally:
         ex.close()
+
+
+@pytest.mark.parametrize("blur,fma", [(2, 0), (0, 1), (2, 1), (1, 1)])
+def test_semantics_variants_equal_oracle(oracle, blur, fma):
+    """The results of the reference depend on the OpenCV version (Gaussian blur) and on whether its
+    build contracts the descriptor's steering sums into fused multiply-adds; every variant is
+    reproduced bit for bit, on widths with and without a tail of width % 4 columns, from host
+    memory and from a tightly pitched device image (the byte-addressed kernels)."""
+    import torch
+    from slam_amd._lib import KP_DTYPE
+    from slam_amd.extractor import ORBextractor
+    p = oracle.params(blur_variant=blur, fma_variant=fma)
+    for w, h in ((640, 480), (642, 480), (517, 389)):
+        ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2, blur_variant=blur, fma_variant=fma)
+        try:
+            imgs = synth.synth_batch(2, w, h, 9000 + w)
+            kps, desc, n = ex.extract_batch(imgs)
+            want = [oracle.extract(p, imgs[f]) for f in range(2)]
+            for f in range(2):
+                assert_same_features(kps[f, :n[f]], desc[f, :n[f]], want[f][0], want[f][1], "%dx%d frame %d" % (w, h, f))
+            for lvl in (0, 3):
+                assert np.array_equal(ex.debug_blurred(1, lvl), oracle.gaussian7(oracle.pyramid_level(p, imgs[1], lvl), blur))
+            cap = ex.max_keypoints()
+            d_img = torch.from_numpy(imgs).cuda()          # pitch = w: unaligned rows when w % 4 != 0
+            d_kps = torch.zeros(2 * cap * 28, dtype=torch.uint8, device="cuda")
+            d_desc = torch.zeros(2 * cap * 32, dtype=torch.uint8, device="cuda")
+            d_n = torch.zeros(2, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ex.extract_batch_device(d_img, d_kps, d_desc, d_n, cap)
+            ex.synchronize()
+            nn = d_n.cpu().numpy()
+            k2 = d_kps.cpu().numpy().view(KP_DTYPE).reshape(2, cap)
+            dd2 = d_desc.cpu().numpy().reshape(2, cap, 32)
+            for f in range(2):
+                assert_same_features(k2[f, :nn[f]], dd2[f, :nn[f]], want[f][0], want[f][1], "device %dx%d frame %d" % (w, h, f))
+        finally:
+            ex.close()
+
+
+def test_variant_mismatch_rates(oracle):
+    """How far the variants are from variant 0 (reported in the design notes): the single-precision
+    blur changes a few pixels per million and a few descriptors per ten thousand; the fused
+    steering sums change a descriptor bit only when a rotated coordinate lands within half an ulp of
+    a rounding boundary."""
+    from slam_amd.extractor import ORBextractor
+    imgs = synth.synth_batch(6, 640, 480, 9500)
+    base = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=6)
+    v2 = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=6, blur_variant=2)
+    vf = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=6, fma_variant=1)
+    try:
+        k0, d0, n0 = base.extract_batch(imgs)
+        k2, d2, n2 = v2.extract_batch(imgs)
+        kf, df, nf = vf.extract_batch(imgs)
+        assert np.array_equal(n0, n2) and np.array_equal(n0, nf)
+        for f in range(6):   # detection and orientation do not depend on either
+            assert k0[f, :n0[f]].tobytes() == k2[f, :n0[f]].tobytes() == kf[f, :n0[f]].tobytes()
+        tot = int(n0.sum())
+        blur_diff = sum(int((d0[f, :n0[f]] != d2[f, :n0[f]]).any(axis=1).sum()) for f in range(6))
+        fma_diff = sum(int((d0[f, :n0[f]] != df[f, :n0[f]]).any(axis=1).sum()) for f in range(6))
+        assert blur_diff < tot // 500 and fma_diff < tot // 500
+    finally:
+        base.close()
+        v2.close()
+        vf.close()
