@@ -973,12 +973,14 @@ __device__ __forceinline__ short4 child_box(short4 b, int q) {
 // sums so that positions, creation order and the stop rule equal those of the
 // sequential algorithm.  Node "addresses" in the size sort are modelled by
 // creation order (later created = greater).
-template <int QT_THREADS>
+// GTAB = false: the node tables live in LDS (72 bytes per list entry); true: in a slice of global
+// memory per (frame, level), for feature counts whose tables do not fit the LDS.
+template <int QT_THREADS, bool GTAB>
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __restrict__ cellCount,
                                                    const u32* __restrict__ slots, u32* keyPacked,
                                                    u16* keyNode, u32* sel, int* selCount,
-                                                   int* errFlag) {
-    extern __shared__ __align__(16) unsigned char smem[];
+                                                   int* errFlag, unsigned char* nodeTables, size_t nodeTableStride) {
+    extern __shared__ __align__(16) unsigned char smemLds[];
     __shared__ QtShared S;
     const int l = blockIdx.x, f = blockIdx.y;
     const LevelGeom& LG = g.lv[l];
@@ -992,7 +994,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     short4* box[2];
     u32* cnt[2];
     u32* seq[2];
-    unsigned char* p = smem;
+    unsigned char* p = smemLds;
+    if (GTAB) p = nodeTables + ((size_t)f * g.nlevels + l) * nodeTableStride;
     box[0] = (short4*)p; p += (size_t)lcap * 8;
     box[1] = (short4*)p; p += (size_t)lcap * 8;
     u32* childCnt = (u32*)p; p += (size_t)lcap * 16;  // 4 per node; reused as u64 best[]
@@ -1107,20 +1110,40 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 C += tot;
             }
         } else {
-            // rank by (count desc, creation order desc)
-            for (int i = tid; i < L; i += QT_THREADS) {
-                const u32 ci = ccnt[i];
-                u16 r = 0xFFFF;
-                if (ci > 1) {
-                    const u64 ki = ((u64)ci << 32) | cseq[i];
-                    int rk = 0;
-                    for (int j = 0; j < L; j++) {
-                        const u32 cj = ccnt[j];
-                        if (cj > 1 && (((u64)cj << 32) | cseq[j]) > ki) rk++;
+            // Rank by (count desc, creation order desc).  Every node that can still be split was pushed
+            // to the front of the list when it was made (only the initial nodes were appended, and those
+            // with more than one key are all split in the first pass), so among the ranked nodes a later
+            // creation means an earlier list position: the order is (count desc, position asc).  A
+            // bitonic sort of count << 32 | ~position over the next power of two; the sort buffer lies
+            // over gpre / newId / moved / rankOf, which are dead here (16 bytes per list entry = room for
+            // twice the list), and only its zero padding overlaps rankOf.
+            u64* srt = (u64*)gpre;
+            int P = 2;
+            while (P < L) P <<= 1;
+            for (int i = tid; i < P; i += QT_THREADS)
+                srt[i] = (i < L && ccnt[i] > 1) ? (((u64)ccnt[i] << 32) | (u64)(0xFFFFFFFFu - (u32)i)) : 0ull;
+            __syncthreads();
+            for (int k = 2; k <= P; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < P; i += QT_THREADS) {
+                        const int x = i ^ j;
+                        if (x > i) {
+                            const u64 a = srt[i], b = srt[x];
+                            const bool desc = (i & k) == 0;   // descending blocks first: the whole ends descending
+                            if (desc ? a < b : a > b) {
+                                srt[i] = b;
+                                srt[x] = a;
+                            }
+                        }
                     }
-                    r = (u16)rk;
+                    __syncthreads();
                 }
-                rankOf[i] = r;
+            }
+            for (int i = tid; i < L; i += QT_THREADS) rankOf[i] = 0xFFFF;
+            __syncthreads();
+            for (int r = tid; r < L; r += QT_THREADS) {
+                const u64 key = srt[r];
+                if (key != 0ull) rankOf[0xFFFFFFFFu - (u32)key] = (u16)r;
             }
             for (int base = 0; base < L; base += QT_THREADS) {
                 const int i = base + tid;
@@ -1675,7 +1698,8 @@ struct orbx_handle {
     // geometry of the current image size
     Geom g;
     bool geomValid = false;
-    size_t qtLds = 0;
+    size_t qtLds = 0;        // bytes of node tables per (frame, level)
+    bool qtGlobal = false;   // tables too large for the LDS: they live in dNodeTables
     int qtThreads = 256;
     ResizeTap* dTaps = nullptr;  // x taps then y taps for each level >= 1
     FastCell* dCells = nullptr;  // one record per FAST cell, all levels
@@ -1691,6 +1715,7 @@ struct orbx_handle {
     u8 *dPyr = nullptr, *dBlur = nullptr;
     u32 *dCellCount = nullptr, *dSlots = nullptr, *dKeyPacked = nullptr, *dSel = nullptr;
     u16* dKeyNode = nullptr;
+    unsigned char *dNodeTables = nullptr, *baseNodeTables = nullptr;  // only with qtGlobal
     int* dSelCount = nullptr;
     // Error word of the kernels (1: quadtree node table full, 2: keypoint capacity per frame too small).
     // It lives in pinned host memory that the device writes directly, so that reading it after a
@@ -1778,9 +1803,9 @@ int device_init_once(int device) {
     if (done[device]) return ORBX_OK;
     int rc = upload_constants_locked();
     if (rc) return rc;
-    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<256>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_MAX_LDS));
-    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<512>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_MAX_LDS));
-    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_MAX_LDS));
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_MAX_LDS));
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_MAX_LDS));
+    ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_quadtree<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, QT_MAX_LDS));
     done[device] = true;
     return ORBX_OK;
 }
@@ -1927,11 +1952,8 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     }
     g.pyrFrameBytes = align_up((int)std::max<i64>(pyrOff, 64), 256);
     g.blurFrameBytes = align_up((int)blurOff, 256);
-    if (maxLds > (size_t)QT_MAX_LDS) {
-        orbx_set_error("nfeatures too large for the quadtree's LDS budget (%zu bytes)", maxLds);
-        return ORBX_ERR_UNSUPPORTED;
-    }
-    h->qtLds = maxLds;
+    h->qtGlobal = maxLds > (size_t)QT_MAX_LDS;
+    h->qtLds = (maxLds + 255) & ~(size_t)255;
     {
         // one workgroup walks all candidates of a level several times and ranks its nodes: levels with
         // thousands of nodes (4K frames with 10^4 features) want more threads than VGA levels do
@@ -2100,6 +2122,8 @@ int ensure_scratch(orbx_handle* h, int batch) {
     ORBX_HIP_CHECK(hipDeviceSynchronize());
     free_dev(h->basePyr); free_dev(h->baseBlur); free_dev(h->baseCellCount); free_dev(h->baseSlots);
     free_dev(h->baseKeyPacked); free_dev(h->baseKeyNode); free_dev(h->baseSel); free_dev(h->baseSelCount);
+    free_dev(h->baseNodeTables);
+    h->baseNodeTables = nullptr;
     h->basePyr = h->baseBlur = nullptr;
     h->baseCellCount = h->baseSlots = h->baseKeyPacked = h->baseSel = nullptr;
     h->baseKeyNode = nullptr;
@@ -2114,6 +2138,7 @@ int ensure_scratch(orbx_handle* h, int batch) {
     ORBX_HIP_CHECK(hipMalloc((void**)&h->baseKeyNode, B * g.totalSlots * sizeof(u16)));
     ORBX_HIP_CHECK(hipMalloc((void**)&h->baseSel, B * g.totalSel * sizeof(u32)));
     ORBX_HIP_CHECK(hipMalloc((void**)&h->baseSelCount, B * ORBX_MAX_LEVELS * sizeof(int)));
+    if (h->qtGlobal) ORBX_HIP_CHECK(hipMalloc((void**)&h->baseNodeTables, B * g.nlevels * h->qtLds));
     h->scratchBatch = batch;
     h->scratchSig = sig;
     return ORBX_OK;
@@ -2130,6 +2155,7 @@ void select_scratch(orbx_handle* h, size_t frame0) {
     h->dKeyNode = h->baseKeyNode + frame0 * g.totalSlots;
     h->dSel = h->baseSel + frame0 * g.totalSel;
     h->dSelCount = h->baseSelCount + frame0 * ORBX_MAX_LEVELS;
+    h->dNodeTables = h->baseNodeTables ? h->baseNodeTables + frame0 * g.nlevels * h->qtLds : nullptr;
 }
 
 // Streams and events of pipe p >= 1, created on first use.
@@ -2273,9 +2299,17 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     {
         StageTimer t(h, ORBX_STAGE_QUADTREE);
         dim3 grid(g.nlevels, n, 1), block(h->qtThreads, 1, 1);
-        auto kq = h->qtThreads == 1024 ? k_quadtree<1024> : h->qtThreads == 512 ? k_quadtree<512> : k_quadtree<256>;
-        hipLaunchKernelGGL(kq, grid, block, h->qtLds, st, g, (const u32*)h->dCellCount,
-                           (const u32*)h->dSlots, h->dKeyPacked, h->dKeyNode, h->dSel, h->dSelCount, h->dErr);
+        if (h->qtGlobal) {
+            // node tables in global memory: one slice per (frame, level) of this pass
+            hipLaunchKernelGGL((k_quadtree<1024, true>), grid, dim3(1024, 1, 1), 0, st, g, (const u32*)h->dCellCount,
+                               (const u32*)h->dSlots, h->dKeyPacked, h->dKeyNode, h->dSel, h->dSelCount, h->dErr,
+                               h->dNodeTables, h->qtLds);
+        } else {
+            auto kq = h->qtThreads == 1024 ? k_quadtree<1024, false> : h->qtThreads == 512 ? k_quadtree<512, false> : k_quadtree<256, false>;
+            hipLaunchKernelGGL(kq, grid, block, h->qtLds, st, g, (const u32*)h->dCellCount,
+                               (const u32*)h->dSlots, h->dKeyPacked, h->dKeyNode, h->dSel, h->dSelCount, h->dErr,
+                               (unsigned char*)nullptr, (size_t)0);
+        }
     }
     if (fork) ORBX_HIP_CHECK(hipStreamWaitEvent(st, h->evBlur, 0));
     {
@@ -2372,6 +2406,7 @@ void orbx_destroy(orbx_handle* h) {
     (void)hipDeviceSynchronize();
     free_dev(h->basePyr); free_dev(h->baseBlur); free_dev(h->baseCellCount); free_dev(h->baseSlots);
     free_dev(h->baseKeyPacked); free_dev(h->baseKeyNode); free_dev(h->baseSel); free_dev(h->baseSelCount);
+    free_dev(h->baseNodeTables);
     for (int p = 1; p < ORBX_PIPES; p++) {
         orbx_handle::Pipe& P = h->pipes[p];
         if (P.st) (void)hipStreamDestroy(P.st);

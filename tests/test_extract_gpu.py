@@ -538,3 +538,22 @@ def test_variant_mismatch_rates(oracle):
         base.close()
         v2.close()
         vf.close()
+
+
+@pytest.mark.parametrize("w,h,nf,kind", [(1280, 960, 20000, "scene"), (960, 720, 30000, "noise"), (1920, 1080, 16000, "scene")])
+def test_feature_counts_beyond_the_lds_node_tables(oracle, w, h, nf, kind):
+    """The reference has no feature limit (src/ORBextractor.cc:540-765).  Quotas whose quadtree
+    node tables do not fit the LDS run with the tables in global memory; same results."""
+    from slam_amd.extractor import ORBextractor
+    if kind == "noise":
+        img = (synth.hash_u64(77, w * h, 3) & np.uint64(255)).astype(np.uint8).reshape(h, w)
+    else:
+        img = synth.synth_image(w, h, 4100 + nf)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    try:
+        kps, desc = ex(img, None)
+        rk, rd = oracle.extract(oracle.params(nfeatures=nf), img, cap=nf + 4096)
+        assert len(rk) > nf // 2
+        assert_same_features(kps, desc, rk, rd, "%dx%d / %d features" % (w, h, nf))
+    finally:
+        ex.close()

@@ -37,7 +37,7 @@ def draw(rng):
     while nl_max < 12 and min(w, h) / scale ** nl_max >= 72:
         nl_max += 1
     nlevels = int(rng.integers(1, nl_max + 1))
-    nf = int(rng.choice([50, 200, 500, 1000, 1500, 3000]))
+    nf = int(rng.choice([50, 200, 500, 1000, 1500, 3000, 8000, 20000]))
     ini = int(rng.integers(4, 70))
     mn = int(rng.integers(1, ini + 1))
     kind = int(rng.integers(0, 5))
