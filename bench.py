@@ -158,25 +158,34 @@ def main():
     # concurrent schedule a stage's wall time also counts what runs beside it); its launch
     # duration for the roofline is the one measured in the timed region above.
     dominant = args.roofline_kernel if args.roofline_kernel != "auto" else max(st2, key=lambda k: st2[k]["ms_total"])
-    traffic = None
+    # HBM traffic and vector-instruction counts come from separate rocprofv3 counter passes
+    # (tools/collect_profiles.sh, tools/collect_sq.sh) whose summaries are committed under profiles/
+    # together with a hash of the kernel sources they were taken with: a summary of other sources is
+    # not quoted.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_hash import kernel_source_hash
+    src_hash = kernel_source_hash()
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if dominant in tj and tj[dominant].get("frames_per_launch") == frames_per_launch:
+            if tj.get("source_hash") != src_hash:
+                traffic_note = "profiles/pmc_traffic.json was taken with other kernel sources (stale): not quoted"
+            elif dominant in tj and tj[dominant].get("frames_per_launch") == frames_per_launch:
                 traffic = tj[dominant]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-    # vector instructions of the dominant kernel per launch, from the committed SQ counter pass (same
-    # 512-frame launches); the kernels on this path are bound by vector-instruction issue, not by HBM
     valu = None
-    spath = os.path.join(ROOT, "profiles", "r1_sq_counters.csv")
+    spath = os.path.join(ROOT, "profiles", "sq_counters.json")
     if os.path.exists(spath) and frames_per_launch == 512:
         try:
             import csv
-            for r in csv.DictReader(open(spath)):
-                if r["kernel"] == KERNEL_OF[dominant]:
-                    valu = float(r["SQ_INSTS_VALU"])
+            sj = json.load(open(spath))
+            if sj.get("source_hash") == src_hash:
+                for r in csv.DictReader(open(os.path.join(ROOT, "profiles", sj["file"]))):
+                    if r["kernel"] == KERNEL_OF[dominant].split(" ")[0]:
+                        valu = float(r["SQ_INSTS_VALU"])
         except Exception:
             valu = None
     alg = ALG_BYTES[dominant]
@@ -187,14 +196,17 @@ def main():
                 "avg_launch_ms": stages[dominant]["ms_per_launch"],
                 "avg_launch_ms_serialized": st2[dominant]["ms_per_launch"],
                 "achieved_serialized": st2[dominant].get("achieved_GBs"),
-                "time_share": round(st2[dominant]["ms_total"] / sum(s["ms_total"] for s in st2.values()), 3)}
+                "time_share": round(st2[dominant]["ms_total"] / sum(s["ms_total"] for s in st2.values()), 3),
+                "kernel_source_hash": src_hash}
+    if traffic_note:
+        roofline["traffic_note"] = traffic_note
     if valu:
         per_s = valu / (st2[dominant]["ms_per_launch"] * 1e-3)
         roofline["valu_issue"] = {"wave_instr_per_launch": int(valu), "wave_instr_per_s_serialized": round(per_s, 1),
                                   "issue_rate_at_4_cycles": round(1024 * 2.4e9 / 4.0, 1),
                                   "frac_of_issue_rate": round(per_s / (1024 * 2.4e9 / 4.0), 3),
-                                  "note": "1024 SIMDs at 2.4 GHz; measured 2.3-2.8 cycles per wave64 instruction for "
-                                          "add/sub/and/xor/fma, 4.1-4.5 for the rest (profiles/r1_probes.txt)"}
+                                  "note": "1024 SIMDs at 2.4 GHz; measured 2.2-2.8 cycles per wave64 instruction for "
+                                          "add/sub/and/or/xor/lshr/bitop3/fma, 4.1-4.5 for the rest (profiles/r2_valu_probe.txt)"}
 
     out = {
         "metric": "ORB frames/s (640x480, 1000kp, 8 lvl)", "value": round(value, 1), "unit": "frames/s",
@@ -234,12 +246,13 @@ def main():
         out["cpu_baseline"] = {"value": round(S / cpu_mt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
                                "sample": "first %d of the benchmark's frames, oracle (C++ restatement of the "
                                          "reference path, not OpenCV), frame-parallel std::thread" % S,
-                               "single_thread_frames_per_s": round(s1 / cpu_1t, 2)}
+                               "single_thread_frames_per_s": round(s1 / cpu_1t, 2), "single_thread_sample_frames": s1}
         s2 = min(64, S)
         st_cpu = O.extract_stages(p, host[:s2])
         tot_cpu = sum(st_cpu.values()) or 1.0
         out["cpu_baseline"]["single_thread_stage_share"] = {k: round(v / tot_cpu, 3) for k, v in st_cpu.items()}
         out["cpu_baseline"]["single_thread_ms_per_frame"] = round(tot_cpu / s2 * 1e3, 2)
+        out["cpu_baseline"]["stage_share_sample_frames"] = s2
         n = d_n[:S].cpu().numpy()
         kps = d_kps[:S * cap * 28].cpu().numpy().view(KP_DTYPE).reshape(S, cap)
         desc = d_desc[:S * cap * 32].cpu().numpy().reshape(S, cap, 32)

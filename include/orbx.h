@@ -444,6 +444,32 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
               int train_index_base, int32_t* best_idx, int32_t* best_d, int32_t* second_d,
               int mem_space);
 
+/* ---- bag-of-words transform ----
+ * DBoW2's vocabulary tree as plain arrays (DBoW2 itself and its vocabulary file are dependencies the
+ * reference does not vendor, Thirdparty/DBoW2/readme.md): node 0 is the root; children of node i
+ * are children[child_start[i] .. child_start[i+1]) in the order of m_nodes[i].children; a node
+ * without children is a word with word_id and weight (TemplatedVocabulary::Node); levels = m_L. */
+typedef struct orbm_vocabulary {
+    int32_t n_nodes;
+    int32_t n_children;          /* entries of `children` (= n_nodes - 1 for a tree) */
+    int32_t levels;              /* m_L */
+    const uint8_t* node_desc;    /* n_nodes x 32 (the root's row is not read) */
+    const int32_t* child_start;  /* n_nodes + 1 */
+    const int32_t* children;     /* n_children */
+    const int32_t* word_id;      /* n_nodes; read for nodes without children */
+    const double* weight;        /* n_nodes; read for nodes without children */
+} orbm_vocabulary;
+
+/* TemplatedVocabulary<FORB::TDescriptor, FORB>::transform(feature, word_id, weight, &nid, levelsup)
+ * for every row of desc: the call Frame::ComputeBoW makes per descriptor (reference
+ * src/Frame.cc:513-522, levelsup = 4).  From the root the feature goes to the closest child in
+ * Hamming distance, the first child on ties, down to a node without children; node_id[i] is the
+ * node passed at level levels - levelsup (0, the root, when that is <= 0).  The BowVector
+ * (sum of weights per word, L1-normalised) and the FeatureVector (features per node, ascending) are
+ * std::map containers the host fills from these three arrays. */
+int orbm_bow_transform(orbm_context* m, const orbm_vocabulary* voc, const uint8_t* desc, int n,
+                       int levelsup, int32_t* word_id, double* weight, int32_t* node_id, int mem_space);
+
 /* The acceptance rule that follows the best / second-best scan in the reference's descriptor
  * loops (src/ORBmatcher.cc:284-288, :561-565): accept[i] = best_d[i] <= max_dist (TH_LOW or
  * TH_HIGH at the call site) && (float)best_d[i] < nn_ratio * (float)second_d[i]. */

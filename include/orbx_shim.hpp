@@ -549,6 +549,40 @@ public:
                     "orbm_window_best");
     }
 
+    // ORBVocabulary::transform(vCurrentDesc, mBowVec, mFeatVec, levelsup) as Frame::ComputeBoW calls it
+    // (reference src/Frame.cc:513-522), with the vocabulary tree given as arrays.  The descent runs
+    // on the GPU; the containers (DBoW2::BowVector and DBoW2::FeatureVector are std::maps) are filled
+    // here with DBoW2's arithmetic for the TF-IDF / L1 vocabulary: weights of a word are added in
+    // feature order, stopped words (weight 0) are left out, the vector is divided by its L1 norm
+    // summed in word order.
+    template <class BowVectorT, class FeatureVectorT>
+    void Transform(const orbm_vocabulary& voc, const unsigned char* descriptors, int n, BowVectorT& v, FeatureVectorT& fv,
+                   int levelsup) {
+        v.clear();
+        fv.clear();
+        if (n <= 0) return;
+        std::vector<int> word(n), node(n);
+        std::vector<double> weight(n);
+        orbx::check(orbm_bow_transform(m_, &voc, descriptors, n, levelsup, word.data(), weight.data(), node.data(), ORBX_MEM_HOST),
+                    "orbm_bow_transform");
+        typedef typename BowVectorT::key_type WordId;
+        typedef typename FeatureVectorT::key_type NodeId;
+        for (int i = 0; i < n; i++) {
+            if (!(weight[i] > 0)) continue;
+            const WordId id = (WordId)word[i];
+            typename BowVectorT::iterator vit = v.lower_bound(id);
+            if (vit != v.end() && !(v.key_comp()(id, vit->first)))
+                vit->second += weight[i];
+            else
+                v.insert(vit, typename BowVectorT::value_type(id, weight[i]));
+            fv[(NodeId)node[i]].push_back((unsigned int)i);
+        }
+        double norm = 0.0;
+        for (typename BowVectorT::iterator it = v.begin(); it != v.end(); ++it) norm += it->second < 0 ? -it->second : it->second;
+        if (norm > 0.0)
+            for (typename BowVectorT::iterator it = v.begin(); it != v.end(); ++it) it->second /= norm;
+    }
+
     // MapPoint::ComputeDistinctiveDescriptors for many map points (reference src/MapPoint.cc:279-341).
     void ComputeDistinctiveDescriptors(const unsigned char* descriptors, const std::vector<int>& groupStart,
                                        std::vector<int>& bestIdx, std::vector<unsigned char>& chosen) {

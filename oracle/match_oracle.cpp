@@ -10,6 +10,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <thread>
 #include <vector>
 
@@ -550,6 +551,69 @@ void oracle_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* best_i
         best_d[i] = bestDist1;
         second_d[i] = bestDist2;
     }
+}
+
+// DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>::transform, restated from the published
+// library (DBoW2/TemplatedVocabulary.h: transform(feature, word_id, weight, nid, levelsup) and
+// transform(features, BowVector, FeatureVector, levelsup)); the reference calls it at
+// src/Frame.cc:513-522 but does not vendor it.  The tree comes as arrays: children of node i are
+// children[child_start[i] .. child_start[i+1]) in the order of m_nodes[i].children.
+void oracle_bow_transform(int n_nodes, int levels, const uint8_t* node_desc, const int* child_start, const int* children,
+                          const int* word_id, const double* weight, const uint8_t* desc, int n, int levelsup, int* word_out,
+                          double* weight_out, int* node_out) {
+    (void)n_nodes;
+    for (int i_feature = 0; i_feature < n; i_feature++) {
+        const uint8_t* feature = desc + (size_t)i_feature * 32;
+        const int nid_level = levels - levelsup;
+        int nid = 0;  // root when nid_level <= 0
+        int final_id = 0;
+        int current_level = 0;
+        do {
+            ++current_level;
+            const int* nodes = children + child_start[final_id];
+            const int nnodes = child_start[final_id + 1] - child_start[final_id];
+            final_id = nodes[0];
+            double best_d = descriptor_distance(feature, node_desc + (size_t)final_id * 32);
+            for (int k = 1; k < nnodes; k++) {
+                const int id = nodes[k];
+                const double d = descriptor_distance(feature, node_desc + (size_t)id * 32);
+                if (d < best_d) {
+                    best_d = d;
+                    final_id = id;
+                }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (child_start[final_id + 1] > child_start[final_id]);  // !isLeaf()
+        word_out[i_feature] = word_id[final_id];
+        weight_out[i_feature] = weight[final_id];
+        node_out[i_feature] = nid;
+    }
+}
+
+// BowVector of the TF / TF_IDF weightings with L1 scoring (the ORB vocabulary): addWeight per
+// feature in feature order for weights > 0, then normalize(L1) in ascending word order.  ids / vals:
+// room for n entries; returns the number of words.
+int oracle_bow_vector(const int* word, const double* weight, int n, int* ids, double* vals) {
+    std::map<int, double> v;
+    for (int i = 0; i < n; i++) {
+        if (weight[i] > 0) {
+            std::map<int, double>::iterator vit = v.lower_bound(word[i]);
+            if (vit != v.end() && !(word[i] < vit->first))
+                vit->second += weight[i];
+            else
+                v.insert(vit, std::make_pair(word[i], weight[i]));
+        }
+    }
+    double norm = 0.0;
+    for (std::map<int, double>::iterator it = v.begin(); it != v.end(); ++it) norm += fabs(it->second);
+    if (norm > 0.0)
+        for (std::map<int, double>::iterator it = v.begin(); it != v.end(); ++it) it->second /= norm;
+    int k = 0;
+    for (std::map<int, double>::iterator it = v.begin(); it != v.end(); ++it, ++k) {
+        ids[k] = it->first;
+        vals[k] = it->second;
+    }
+    return k;
 }
 
 // The same scan with the queries split over host threads (every query is still one serial scan).

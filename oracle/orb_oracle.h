@@ -181,6 +181,10 @@ int oracle_search_by_sim3(const oracle_frame* kf1, const oracle_frame* kf2, cons
 /* Brute-force 2-nearest search with the serial-scan semantics of the
  * reference's descriptor loops (src/ORBmatcher.cc:260-288): strict '<'
  * updates, second-best may equal best, ratio and TH_LOW tests. */
+void oracle_bow_transform(int n_nodes, int levels, const uint8_t* node_desc, const int* child_start, const int* children,
+                          const int* word_id, const double* weight, const uint8_t* desc, int n, int levelsup, int* word_out,
+                          double* weight_out, int* node_out);
+int oracle_bow_vector(const int* word, const double* weight, int n, int* ids, double* vals);
 void oracle_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int* best_idx, int* best_d,
                  int* second_d);
 void oracle_knn2_mt(const uint8_t* q, int nq, const uint8_t* t, int nt, int* best_idx, int* best_d,

@@ -361,6 +361,35 @@ def knn2(q, t, threads=1):
     return bi, bd, sd
 
 
+# ---------------------------------------------------------------- DBoW2 transform
+def bow_transform(voc, desc, levelsup=4):
+    """voc: dict with levels, node_desc (n, 32) u8, child_start (n+1) i32, children i32, word_id i32,
+    weight f64.  Returns (word, weight, node) per descriptor."""
+    nd = np.ascontiguousarray(voc["node_desc"], np.uint8)
+    cs = np.ascontiguousarray(voc["child_start"], np.int32)
+    ch = np.ascontiguousarray(voc["children"], np.int32)
+    wi = np.ascontiguousarray(voc["word_id"], np.int32)
+    wt = np.ascontiguousarray(voc["weight"], np.float64)
+    d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(d)
+    word, node = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    weight = np.zeros(max(n, 1), np.float64)
+    f = lib().oracle_bow_transform
+    f.restype = None
+    f(len(nd), int(voc["levels"]), _p(nd), _p(cs), _p(ch), _p(wi), _p(wt), _p(d), n, int(levelsup), _p(word), _p(weight),
+      _p(node))
+    return word[:n], weight[:n], node[:n]
+
+
+def bow_vector(word, weight):
+    word = np.ascontiguousarray(word, np.int32)
+    weight = np.ascontiguousarray(weight, np.float64)
+    ids = np.zeros(max(len(word), 1), np.int32)
+    vals = np.zeros(max(len(word), 1), np.float64)
+    k = lib().oracle_bow_vector(_p(word), _p(weight), len(word), _p(ids), _p(vals))
+    return ids[:k].copy(), vals[:k].copy()
+
+
 # ---------------------------------------------------------------- vocabulary-guided searches
 class FeatVec(C.Structure):
     _fields_ = [("n_nodes", C.c_int), ("node_ids", C.c_void_p), ("start", C.c_void_p), ("items", C.c_void_p)]

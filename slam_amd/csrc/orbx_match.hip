@@ -2128,6 +2128,58 @@ __global__ void k_knn2_merge(int nq, int* ia, int* da, int* sa, const int* ib, c
     sa[i] = s;
 }
 
+// DBoW2 TemplatedVocabulary::transform for one feature (the published algorithm behind the call at
+// reference src/Frame.cc:513-522): from the root, go to the child whose descriptor is closest in
+// Hamming distance (the first child on ties, strict '<'), until a node without children; report its
+// word id, its weight and the node passed at level nidLevel (the root, 0, when nidLevel <= 0).
+// Sixteen lanes per feature: each takes children c, c + 16, ... of the current node.
+struct DevVocabulary {
+    int nNodes;
+    const u8* nodeDesc;
+    const int* childStart;
+    const int* children;
+    const int* wordId;
+    const double* weight;
+};
+__global__ __launch_bounds__(256) void k_bow_transform(DevVocabulary V, const u8* __restrict__ desc, int n, int nidLevel,
+                                                        int* __restrict__ wordOut, double* __restrict__ weightOut,
+                                                        int* __restrict__ nodeOut) {
+    const int lane16 = threadIdx.x & 15;
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const bool live = i < n;
+    const uint4* fd = (const uint4*)(desc + (i64)(live ? i : 0) * 32);
+    const uint4 f0 = fd[0], f1 = fd[1];
+    int node = 0, nid = 0, level = 0;
+    // every lane of a group follows the same path; groups of a wave may differ in depth, so the loop
+    // runs while any group is still descending and finished groups idle (bounded by the tree depth)
+    bool going = live;
+    for (int guard = 0; guard < 64; guard++) {
+        const int b = going ? V.childStart[node] : 0, e = going ? V.childStart[node + 1] : 0;
+        if (e <= b) going = false;  // a leaf
+        if (!__any(going)) break;
+        u32 best = 0xFFFFFFFFu;     // distance << 16 | position in the children list
+        if (going) {
+            for (int c = b + lane16; c < e; c += 16) {
+                const uint4* nd = (const uint4*)(V.nodeDesc + (i64)V.children[c] * 32);
+                const u32 d = (u32)hamming256(f0, f1, nd[0], nd[1]);
+                best = min(best, (d << 16) | (u32)(c - b));
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) best = min(best, (u32)__shfl_xor((int)best, o, 16));
+        if (going) {
+            node = V.children[b + (int)(best & 0xFFFFu)];
+            level++;
+            if (level == nidLevel) nid = node;
+        }
+    }
+    if (live && lane16 == 0) {
+        wordOut[i] = V.wordId[node];
+        weightOut[i] = V.weight[node];
+        nodeOut[i] = nid;
+    }
+}
+
 // Acceptance rule of the reference's descriptor loops (src/ORBmatcher.cc:284-288): best <= th and
 // (float)best < ratio * (float)second.
 __global__ void k_ratio_test(int nq, const int* __restrict__ bd, const int* __restrict__ sd, float ratio, int th, u8* accept) {
@@ -2259,7 +2311,8 @@ enum {
     SL_ST_U, SL_ST_D, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, SL_BW_VALID1,
     SL_BW_VALID2, SL_BW_M12, SL_BW_M21, SL_BW_BIN, SL_BW_HIST, SL_BW_UR1, SL_BW_UR2, SL_WB_LEVEL, SL_WB_IDX, SL_WB_DIST,
     SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2, SL_DD_DESC, SL_DD_START, SL_DD_BEST, SL_DD_MED, SL_DD_OUT,
-    SL_MK_MASK, SL_MK_KPS, SL_MK_DESC, SL_RC_REC, SL_RC_IDX, SL_JB_JOBS, SL_JB_I32, SL_JB_U8, SL_JB_TOT, SL_JB_SF, SL_JB_SLAB, SL_SORTED
+    SL_MK_MASK, SL_MK_KPS, SL_MK_DESC, SL_RC_REC, SL_RC_IDX, SL_JB_JOBS, SL_JB_I32, SL_JB_U8, SL_JB_TOT, SL_JB_SF, SL_JB_SLAB, SL_SORTED,
+    SL_BT_DESC, SL_BT_START, SL_BT_CHILD, SL_BT_WORD, SL_BT_WEIGHT, SL_BT_FEAT, SL_BT_OUTW, SL_BT_OUTV, SL_BT_OUTN
 };
 
 // Device view of a caller array: the pointer itself for device memory, else a staged copy.
@@ -3646,6 +3699,55 @@ int orbm_knn2_noalloc(orbm_context* m, const uint8_t* q, int nq, const uint8_t* 
     hipLaunchKernelGGL(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, slices, (const int*)pi,
                        (const int*)pd, (const int*)ps, (int*)best_idx, (int*)best_d, (int*)second_d);
     ORBX_HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbm_bow_transform(orbm_context* m, const orbm_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int32_t* word_id,
+                       double* weight, int32_t* node_id, int mem_space) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (!voc || n < 0 || !word_id || !weight || !node_id || (n > 0 && !desc) || voc->n_nodes < 1 || !voc->node_desc ||
+        !voc->child_start || !voc->word_id || !voc->weight || (voc->n_children > 0 && !voc->children)) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (n == 0) return ORBX_OK;
+    if (mem_space == ORBX_MEM_HOST) {
+        // host tables can be checked: offsets monotone, children in range, a child list of at most 65535 entries
+        for (int i = 0; i < voc->n_nodes; i++) {
+            const int b = voc->child_start[i], e = voc->child_start[i + 1];
+            if (b < 0 || e < b || e > voc->n_children || e - b > 65535) {
+                orbx_set_error("vocabulary: bad child list of node %d", i);
+                return ORBX_ERR_INVALID;
+            }
+        }
+        for (int c = 0; c < voc->n_children; c++)
+            if (voc->children[c] <= 0 || voc->children[c] >= voc->n_nodes) {
+                orbx_set_error("vocabulary: child entry %d names node %d of %d", c, voc->children[c], voc->n_nodes);
+                return ORBX_ERR_INVALID;
+            }
+    }
+    DevVocabulary V;
+    V.nNodes = voc->n_nodes;
+    if ((rc = stage_in(m, SL_BT_DESC, voc->node_desc, (size_t)voc->n_nodes * 32, mem_space, &V.nodeDesc))) return rc;
+    if ((rc = stage_in(m, SL_BT_START, (const int*)voc->child_start, (size_t)voc->n_nodes + 1, mem_space, &V.childStart))) return rc;
+    if ((rc = stage_in(m, SL_BT_CHILD, (const int*)voc->children, (size_t)std::max(voc->n_children, 1), mem_space, &V.children))) return rc;
+    if ((rc = stage_in(m, SL_BT_WORD, (const int*)voc->word_id, (size_t)voc->n_nodes, mem_space, &V.wordId))) return rc;
+    if ((rc = stage_in(m, SL_BT_WEIGHT, voc->weight, (size_t)voc->n_nodes, mem_space, &V.weight))) return rc;
+    const u8* dDesc;
+    if ((rc = stage_in(m, SL_BT_FEAT, desc, (size_t)n * 32, mem_space, &dDesc))) return rc;
+    int *dWord, *dNode;
+    double* dWeight;
+    if ((rc = stage_out(m, SL_BT_OUTW, (int*)word_id, (size_t)n, mem_space, &dWord))) return rc;
+    if ((rc = stage_out(m, SL_BT_OUTV, weight, (size_t)n, mem_space, &dWeight))) return rc;
+    if ((rc = stage_out(m, SL_BT_OUTN, (int*)node_id, (size_t)n, mem_space, &dNode))) return rc;
+    ORBM_LAUNCH(k_bow_transform, dim3((n * 16 + 255) / 256), dim3(256), 0, m->stream, V, dDesc, n, voc->levels - levelsup, dWord,
+                dWeight, dNode);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(m, (int*)word_id, (const int*)dWord, (size_t)n, mem_space))) return rc;
+    if ((rc = copy_back(m, weight, (const double*)dWeight, (size_t)n, mem_space))) return rc;
+    if ((rc = copy_back(m, (int*)node_id, (const int*)dNode, (size_t)n, mem_space))) return rc;
+    if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
 }
 

@@ -474,6 +474,44 @@ class ORBmatcher:
         s = np.asarray(second_d)
         return (b <= th) & (b.astype(np.float32) < np.float32(self.mfNNratio) * s.astype(np.float32))
 
+    # ---- DBoW2 transform (the call of Frame::ComputeBoW, reference src/Frame.cc:513-522)
+    def BowTransform(self, voc, descriptors, levelsup=4):
+        """TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup) with the
+        vocabulary given as arrays (dict: levels, node_desc, child_start, children, word_id, weight).
+        The tree descent runs on the GPU; the two std::map containers are filled on the host with
+        DBoW2's arithmetic (TF-IDF accumulation in feature order, L1 normalisation in word order).
+        Returns (bow_ids, bow_values, {node id: [feature indices]})."""
+        nd = np.ascontiguousarray(voc["node_desc"], np.uint8)
+        cs = np.ascontiguousarray(voc["child_start"], np.int32)
+        ch = np.ascontiguousarray(voc["children"], np.int32)
+        wi = np.ascontiguousarray(voc["word_id"], np.int32)
+        wt = np.ascontiguousarray(voc["weight"], np.float64)
+        d = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n = len(d)
+        cv = _lib.Vocabulary(len(nd), len(ch), int(voc["levels"]), nd.ctypes.data, cs.ctypes.data, ch.ctypes.data,
+                             wi.ctypes.data, wt.ctypes.data)
+        word, node = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        weight = np.zeros(max(n, 1), np.float64)
+        check(self._lib.orbm_bow_transform(self._m, C.byref(cv), d.ctypes.data, n, int(levelsup), word.ctypes.data,
+                                           weight.ctypes.data, node.ctypes.data, MEM_HOST))
+        word, weight, node = word[:n], weight[:n], node[:n]
+        bow = {}
+        fv = {}
+        for i in range(n):
+            w = float(weight[i])
+            if w > 0:                      # not a stopped word
+                k = int(word[i])
+                bow[k] = bow[k] + w if k in bow else w
+                fv.setdefault(int(node[i]), []).append(i)
+        ids = np.array(sorted(bow), np.int32)
+        vals = np.array([bow[int(k)] for k in ids], np.float64)
+        norm = 0.0
+        for v in vals:                     # sequential, ascending word id, as BowVector::normalize does
+            norm += abs(float(v))
+        if norm > 0.0:
+            vals = vals / norm
+        return ids, vals, fv
+
     def ratio_test_device(self, best_d, second_d, accept, th=None):
         """Device form of ratio_test on torch tensors: int32 (nq,), int32 (nq,), uint8 (nq,) out."""
         check(self._lib.orbm_ratio_test(self._m, best_d.shape[0], best_d.data_ptr(), second_d.data_ptr(),

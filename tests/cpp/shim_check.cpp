@@ -77,6 +77,33 @@ int main(int argc, char** argv) {
             int nb = bow.SearchByBoW(vl, fvL, all.data(), vr, fvR, nullptr, false, m12, m21);
             std::fwrite(&nb, 4, 1, o);
             std::fwrite(m12.data(), 4, m12.size(), o);
+            // Frame::ComputeBoW (reference src/Frame.cc:513-522) on a one-level stand-in vocabulary whose 16
+            // words are the first 16 left descriptors
+            const int nw = 16;
+            std::vector<unsigned char> nodeDesc((size_t)(nw + 1) * 32, 0);
+            std::vector<int> childStart(nw + 2, nw), children(nw), wordId(nw + 1, -1);
+            std::vector<double> weight(nw + 1, 0.0);
+            childStart[0] = 0;
+            for (int i = 0; i < nw; i++) {
+                std::memcpy(&nodeDesc[(size_t)(i + 1) * 32], &desc[(size_t)i * 32], 32);
+                children[i] = i + 1;
+                wordId[i + 1] = i;
+                weight[i + 1] = 1.0 + 0.125 * i;
+            }
+            orbm_vocabulary voc = {nw + 1, nw, 1, nodeDesc.data(), childStart.data(), children.data(), wordId.data(), weight.data()};
+            std::map<unsigned, double> mBowVec;
+            std::map<unsigned, std::vector<unsigned> > mFeatVec;
+            bow.Transform(voc, desc.data(), n, mBowVec, mFeatVec, 0);
+            const int nv = (int)mBowVec.size();
+            std::fwrite(&nv, 4, 1, o);
+            for (std::map<unsigned, double>::iterator it = mBowVec.begin(); it != mBowVec.end(); ++it) {
+                std::fwrite(&it->first, 4, 1, o);
+                std::fwrite(&it->second, 8, 1, o);
+            }
+            unsigned long nfeat = 0;
+            for (std::map<unsigned, std::vector<unsigned> >::iterator it = mFeatVec.begin(); it != mFeatVec.end(); ++it)
+                nfeat += it->first * 1000003ul + it->second.size() * 7ul + it->second.back();
+            std::fwrite(&nfeat, 8, 1, o);
         }
         std::fclose(o);
         std::printf("%d keypoints\n", n);

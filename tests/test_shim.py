@@ -94,6 +94,20 @@ def test_shim_stereo_matches_ctypes(tmp_path):
                                   FrameView(kr, dr, (0, 0, 640, 480), sf), fvr)
     mb.close()
     assert nb == nb2 and nb > 100 and np.array_equal(m12, m12b)
+    # ComputeBoW through the shim's Transform against the ctypes path, same stand-in vocabulary
+    bw = rest[4 + 4 * n:]
+    nv = int(np.frombuffer(bw[:4], np.int32)[0])
+    pairs = np.frombuffer(bw[4:4 + 12 * nv], np.dtype([("id", "<u4"), ("v", "<f8")]))
+    chk = int(np.frombuffer(bw[4 + 12 * nv:12 + 12 * nv], np.uint64)[0])
+    nw = 16
+    voc = dict(levels=1, node_desc=np.concatenate([np.zeros((1, 32), np.uint8), dl[:nw]]),
+               child_start=np.array([0] + [nw] * (nw + 1), np.int32), children=np.arange(1, nw + 1, dtype=np.int32),
+               word_id=np.array([-1] + list(range(nw)), np.int32),
+               weight=np.array([0.0] + [1.0 + 0.125 * i for i in range(nw)], np.float64))
+    ids, vals, fv = m.BowTransform(voc, dl, 0)
+    assert nv == len(ids) == nw and np.array_equal(pairs["id"], ids.astype(np.uint32))
+    assert np.array_equal(pairs["v"].view(np.uint64), vals.view(np.uint64))
+    assert chk == sum(k * 1000003 + len(v) * 7 + v[-1] for k, v in fv.items())
     m.close()
     el.close()
     er.close()

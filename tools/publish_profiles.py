@@ -28,5 +28,14 @@ for k, t in summ["traffic"].items():
                         "frames_per_launch": t["frames_per_launch"],
                         "read_bytes_corrected": t["read_bytes_corrected"] * mult,
                         "write_bytes": t["write_bytes"] * mult}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hash import kernel_source_hash  # noqa: E402
+out["source_hash"] = kernel_source_hash()
+out["tag"] = tag
 json.dump(out, open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
+sq = os.path.join("gpurun_out", "sq_" + tag, "sq_summary.csv")
+if os.path.exists(sq):
+    shutil.copy(sq, os.path.join("profiles", "%s_sq_counters.csv" % tag))
+    json.dump({"tag": tag, "source_hash": out["source_hash"], "file": "%s_sq_counters.csv" % tag},
+              open(os.path.join("profiles", "sq_counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
