@@ -444,6 +444,11 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
               int train_index_base, int32_t* best_idx, int32_t* best_d, int32_t* second_d,
               int mem_space);
 
+/* Debug tap: which form of the scan orbm_knn2 runs.  0 = chosen by problem size (the default),
+ * 1 = vector ALU (xor + popcount), 2 = matrix cores (int8 contraction).  Both give the same
+ * results; the tap exists so that tests and measurements can run either on any size. */
+int orbm_debug_knn_path(orbm_context* m, int path);
+
 /* ---- bag-of-words transform ----
  * DBoW2's vocabulary tree as plain arrays (DBoW2 itself and its vocabulary file are dependencies the
  * reference does not vendor, Thirdparty/DBoW2/readme.md): node 0 is the root; children of node i

@@ -139,6 +139,7 @@ SIGNATURES = {
     "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
     "orbm_bow_transform": (_i, [_vp, C.POINTER(Vocabulary), _vp, _i, _i, _vp, _vp, _vp, _i]),
     "orbm_ratio_test": (_i, [_vp, _i, _vp, _vp, _f, _i, _vp, _i]),
+    "orbm_debug_knn_path": (_i, [_vp, _i]),
     "orbm_knn2_noalloc": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "orbm_knn2_merge": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
 }

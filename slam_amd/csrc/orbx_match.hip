@@ -9,6 +9,7 @@
 // dense contraction, so the matrix cores are not used.
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -2113,6 +2114,181 @@ __global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int n
     }
 }
 
+
+// ---- brute-force 2-NN on the matrix cores
+// With a train descriptor a as 256 values 0 / 1 and a query q as 256 values +1 (bit clear) / -1
+// (bit set), hamming(a, q) = popcount(q) + <a, q>: a contraction of small integers, exact in the
+// block-scaled fp4 form of the matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1
+// operands 0, 1.0, -1.0, unit scales and f32 accumulation; four steps of K = 64 per pair of
+// descriptors, twice the rate of the int8 form and half its operand bytes).  A wave keeps KNN_MQ
+// tiles of 32 queries expanded in registers (B operand: the query is the column, i.e. the lane).
+// The four waves of a block share the train rows: stages of KNN_MROWS rows are expanded once per
+// block through a 256-entry table (a byte -> eight nibbles) into a double-buffered LDS tile, from
+// which every wave reads its A operands.  A 32 x 32 result tile leaves 16 train rows of one query
+// in a lane, so the two smallest (distance, row) keys are kept per lane and query tile as in
+// k_knn2 and the two lanes that share a query are folded at the end.  The position of a bit inside
+// the contraction is arbitrary: both operands use the same one (descriptor byte 8 s + 4 h + i / 8,
+// bit i % 8 at step s, lane half h, element i).
+#define KNN_MQ 4
+#define KNN_MROWS 64
+#define KNN_MPITCH 144  // bytes per expanded row: 128 + 16, so that 16-byte reads down 16 rows touch every bank once
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// the eight nibbles (e2m1 1.0 = 0x2 where the bit is set) of each of the four bytes of w
+__device__ __forceinline__ uint4 knn_nibbles(const u32* lut, const u32 w) {
+    return make_uint4(lut[w & 0xFFu], lut[(w >> 8) & 0xFFu], lut[(w >> 16) & 0xFFu], lut[w >> 24]);
+}
+
+template <bool TAIL>
+__device__ __forceinline__ void knn_fold16(const v16f acc, const int pq, const int row0, const int nt, u32& best, u32& second,
+                                           float& thr) {
+    // key = distance << KNN_IDX_BITS | row with distance = popcount(query) + acc
+    const u32 k0 = ((u32)pq << KNN_IDX_BITS) + (u32)row0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int off = (r & 3) + 8 * (r >> 2);
+        u32 key = ((u32)(int)acc[r] << KNN_IDX_BITS) + (k0 + (u32)off);
+        if (TAIL) key = row0 + off < nt ? key : 0xFFFFFFFFu;
+        second = umed3(best, second, key);
+        best = min(best, key);
+    }
+    thr = (float)((int)(second >> KNN_IDX_BITS) - pq);
+}
+
+__global__ __launch_bounds__(256) void k_knn2_mfma(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt,
+                                                    int indexBase, int* bestIdx, int* bestD, int* secondD, int mergeWithOutput,
+                                                    int sliceRows) {
+    __shared__ u32 lut[256];
+    __shared__ __align__(16) u8 tile[2][KNN_MROWS * KNN_MPITCH];
+    if (sliceRows > 0) {
+        // few queries: blockIdx.y takes a slice of the train rows and writes its own partial results
+        const int r0 = (int)blockIdx.y * sliceRows;
+        t += (i64)r0 * 2;
+        nt = min(sliceRows, nt - r0);
+        indexBase += r0;
+        bestIdx += (i64)blockIdx.y * nq;
+        bestD += (i64)blockIdx.y * nq;
+        secondD += (i64)blockIdx.y * nq;
+    }
+    {
+        const u32 i = threadIdx.x;
+        u32 e = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) e |= ((i >> j) & 1u) << (4 * j + 1);
+        lut[i] = e;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wv) * (32 * KNN_MQ);
+    // waves past the last query keep staging train rows and meeting the barriers; they hold a copy of the last query
+    v4i Bq[KNN_MQ][4];
+    int pq[KNN_MQ];
+#pragma unroll
+    for (int m = 0; m < KNN_MQ; m++) {
+        const int qi = min(q0 + 32 * m + c, nq - 1);
+        const uint4 a = q[(i64)qi * 2], b = q[(i64)qi * 2 + 1];
+        const u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        pq[m] = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) pq[m] += __popc(w[k]);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            // +1.0 (0x2) where the bit is clear, -1.0 (0xA) where it is set
+            const uint4 e = knn_nibbles(lut, w[2 * s] ^ ((w[2 * s] ^ w[2 * s + 1]) & (0u - (u32)h)));
+            Bq[m][s] = (v4i){(int)(0x22222222u | (e.x << 2)), (int)(0x22222222u | (e.y << 2)), (int)(0x22222222u | (e.z << 2)),
+                             (int)(0x22222222u | (e.w << 2))};
+        }
+    }
+    u32 best[KNN_MQ], second[KNN_MQ];
+    float thr[KNN_MQ];
+#pragma unroll
+    for (int m = 0; m < KNN_MQ; m++) {
+        best[m] = second[m] = 0xFFFFFFFFu;
+        thr[m] = 1e9f;
+    }
+    // staging role of this thread: row sr of the stage, descriptor bytes 8 sp .. 8 sp + 7
+    const int sr = threadIdx.x >> 2, sp = threadIdx.x & 3;
+    const uint2* t2 = (const uint2*)t;
+    const int nStages = (nt + KNN_MROWS - 1) / KNN_MROWS;
+    u8* const myDst = &tile[0][0] + sr * KNN_MPITCH + sp * 32;
+    const u8* const mySrc = &tile[0][0] + c * KNN_MPITCH + h * 16;
+    auto stage = [&](u8* dst, const uint2 raw) {
+        *(uint4*)dst = knn_nibbles(lut, raw.x);
+        *(uint4*)(dst + 16) = knn_nibbles(lut, raw.y);
+    };
+    stage(myDst, t2[(i64)min(sr, nt - 1) * 4 + sp]);
+    uint2 pre = t2[(i64)min(KNN_MROWS + sr, nt - 1) * 4 + sp];
+    __syncthreads();
+    const int unit = 0x7F7F7F7F;  // block scales 2^0
+    for (int st = 0; st < nStages; st++) {
+        const int buf = (st & 1) * (KNN_MROWS * KNN_MPITCH);
+        // the next stage goes into the other buffer (last read before the barrier that ended the previous stage)
+        if (st + 1 < nStages) stage(myDst + ((KNN_MROWS * KNN_MPITCH) - buf), pre);
+        pre = t2[(i64)min((st + 2) * KNN_MROWS + sr, nt - 1) * 4 + sp];
+        const bool tail = (st + 1) * KNN_MROWS > nt;
+#pragma unroll
+        for (int sub = 0; sub < KNN_MROWS / 32; sub++) {
+            v4i At[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) At[s] = *(const v4i*)(mySrc + buf + sub * 32 * KNN_MPITCH + s * 32);
+            // result register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 h of the sub-tile
+            const int row0 = st * KNN_MROWS + sub * 32 + 4 * h;
+#pragma unroll
+            for (int m = 0; m < KNN_MQ; m++) {
+                v16f acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const v8i a8 = {At[s][0], At[s][1], At[s][2], At[s][3], 0, 0, 0, 0};
+                    const v8i b8 = {Bq[m][s][0], Bq[m][s][1], Bq[m][s][2], Bq[m][s][3], 0, 0, 0, 0};
+                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc, 4, 4, 0, unit, 0, unit);
+                }
+                // a row can change this lane's two smallest only if its distance is below the second one held
+                float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) mn = fminf(fminf(mn, acc[r]), acc[r + 1]);
+                mn = fminf(mn, acc[15]);
+                if (__any(mn < thr[m])) {
+                    if (tail)
+                        knn_fold16<true>(acc, pq[m], row0, nt, best[m], second[m], thr[m]);
+                    else
+                        knn_fold16<false>(acc, pq[m], row0, nt, best[m], second[m], thr[m]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < KNN_MQ; m++) {
+        // fold the two lanes of a query: smallest and second smallest key of the union
+        const u32 ob = (u32)__shfl_xor((int)best[m], 32), os = (u32)__shfl_xor((int)second[m], 32);
+        const u32 b = min(best[m], ob);
+        const u32 s2 = min(max(best[m], ob), min(second[m], os));
+        const int qi = q0 + 32 * m + c;
+        if (h == 0 && qi < nq) {
+            int bd = b == 0xFFFFFFFFu ? 256 : (int)(b >> KNN_IDX_BITS);
+            int bi = (bd >= 256) ? -1 : (int)(b & ((1u << KNN_IDX_BITS) - 1)) + indexBase;
+            int sd = s2 == 0xFFFFFFFFu ? 256 : (int)(s2 >> KNN_IDX_BITS);
+            bd = min(bd, 256);
+            sd = min(sd, 256);
+            if (mergeWithOutput) {
+                const int pb = bestD[qi], ps = secondD[qi], pi = bestIdx[qi];
+                const int s3 = min(max(pb, bd), min(ps, sd));
+                if (!(bd < pb)) {
+                    bd = pb;
+                    bi = pi;
+                }
+                sd = s3;
+            }
+            bestIdx[qi] = bi;
+            bestD[qi] = bd;
+            secondD[qi] = sd;
+        }
+    }
+}
+
 // Serial scan over shard A then shard B, reproduced from the two partials:
 // best = min (A wins ties: lower global index); second = second smallest of
 // the union multiset = min(max(bestA, bestB), secondA, secondB).
@@ -2250,7 +2426,8 @@ struct orbm_context {
     // grow-only scratch, one block per purpose
     std::vector<std::pair<void*, size_t>> pool;
     std::vector<int> totalsHost;
-    bool resolveLdsReady = false, resolveJobsLdsReady = false, initSortedReady = false, distinctiveReady = false;  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
+    bool resolveLdsReady = false, resolveJobsLdsReady = false, initSortedReady = false, distinctiveReady = false;
+    int knnPath = 0;  // 0 = by size, 1 = vector ALU, 2 = matrix cores (orbm_debug_knn_path)  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
     // Host arrays travel through one pinned arena per call: copies from and to pageable memory are staged
     // and serialised by the runtime (10-15 us each), copies from pinned memory are plain queue entries.
     // Results land in the arena and are handed to the caller's arrays after the stream has been waited for.
@@ -3622,28 +3799,41 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
     if ((rc = stage_out(m, SL_KNN_I, (int*)best_idx, (size_t)nq, mem_space, &di))) return rc;
     if ((rc = stage_out(m, SL_KNN_D, (int*)best_d, (size_t)nq, mem_space, &dd))) return rc;
     if ((rc = stage_out(m, SL_KNN_S, (int*)second_d, (size_t)nq, mem_space, &ds))) return rc;
-    const int blocks = (nq + 256 * KNN_QPT - 1) / (256 * KNN_QPT);
     const int chunkRows = 1 << KNN_IDX_BITS;
-    if (blocks < 128 && nt >= 128 && nt <= chunkRows) {
+    // Two forms of the same scan: on the matrix cores (an exact int8 contraction) when the problem is
+    // large enough to pay for the expansion of bits to bytes, on the vector ALU (xor + popcount) otherwise.
+    const bool mfma = m->knnPath == 2 || (m->knnPath == 0 && nq >= 512 && nt >= 512 && (i64)nq * nt >= ((i64)1 << 24));
+    const int blocks = mfma ? (nq + 4 * 32 * KNN_MQ - 1) / (4 * 32 * KNN_MQ) : (nq + 256 * KNN_QPT - 1) / (256 * KNN_QPT);
+    const int rowQuantum = mfma ? KNN_MROWS : 8;
+    if (blocks < (mfma ? 512 : 128) && nt >= 128 && nt <= chunkRows) {
         // too few queries to fill the GPU: the train rows are split over blockIdx.y and the partials folded in order
-        int slices = std::min(nt / 32, std::max(1024 / blocks, 1));
-        const int sliceRows = ((nt + slices - 1) / slices + 7) & ~7;
+        int slices = std::min(nt / (mfma ? 2 * KNN_MROWS : 32), std::max((mfma ? 2048 : 1024) / blocks, 1));
+        slices = std::max(slices, 1);
+        const int sliceRows = ((nt + slices - 1) / slices + rowQuantum - 1) / rowQuantum * rowQuantum;
         slices = (nt + sliceRows - 1) / sliceRows;
         void *pi, *pd, *ps;
         const size_t partBytes = (size_t)slices * nq * sizeof(int);
         if ((rc = pool_get(m, SL_KNN_I2, partBytes, &pi)) || (rc = pool_get(m, SL_KNN_D2, partBytes, &pd)) ||
             (rc = pool_get(m, SL_KNN_S2, partBytes, &ps)))
             return rc;
-        ORBM_LAUNCH(k_knn2, dim3(blocks, slices), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt, nt,
-                    train_index_base, (int*)pi, (int*)pd, (int*)ps, 0, sliceRows);
+        if (mfma)
+            ORBM_LAUNCH(k_knn2_mfma, dim3(blocks, slices), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt, nt,
+                        train_index_base, (int*)pi, (int*)pd, (int*)ps, 0, sliceRows);
+        else
+            ORBM_LAUNCH(k_knn2, dim3(blocks, slices), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt, nt,
+                        train_index_base, (int*)pi, (int*)pd, (int*)ps, 0, sliceRows);
         ORBM_LAUNCH(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, slices, (const int*)pi,
                     (const int*)pd, (const int*)ps, di, dd, ds);
     } else {
         int c0 = 0;
         do {
             const int rows = std::min(chunkRows, nt - c0);
-            ORBM_LAUNCH(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)(dt + (size_t)c0 * 32),
-                        rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0, 0);
+            if (mfma && rows > 0)
+                ORBM_LAUNCH(k_knn2_mfma, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq,
+                            (const uint4*)(dt + (size_t)c0 * 32), rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0, 0);
+            else
+                ORBM_LAUNCH(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)(dt + (size_t)c0 * 32),
+                            rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0, 0);
             c0 += rows;
         } while (c0 < nt);
     }
@@ -3652,6 +3842,15 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
     if ((rc = copy_back(m, (int*)best_d, (const int*)dd, (size_t)nq, mem_space))) return rc;
     if ((rc = copy_back(m, (int*)second_d, (const int*)ds, (size_t)nq, mem_space))) return rc;
     if (mem_space == ORBX_MEM_HOST) ORBX_HIP_CHECK(sync_deliver(m));
+    return ORBX_OK;
+}
+
+int orbm_debug_knn_path(orbm_context* m, int path) {
+    if (!m || path < 0 || path > 2) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    m->knnPath = path;
     return ORBX_OK;
 }
 

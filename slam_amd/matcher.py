@@ -441,6 +441,10 @@ class ORBmatcher:
                                   bi.ctypes.data, bd.ctypes.data, sd.ctypes.data, MEM_HOST))
         return bi[:nq], bd[:nq], sd[:nq]
 
+    def debug_knn_path(self, path):
+        """0 = scan chosen by size, 1 = vector ALU, 2 = matrix cores (same results either way)."""
+        check(self._lib.orbm_debug_knn_path(self._m, int(path)))
+
     def knn2_device(self, q, t, best_idx, best_d, second_d, index_base=0):
         """torch tensors on the device: q (nq, 32) u8, t (nt, 32) u8, int32 outputs (nq,)."""
         check(self._lib.orbm_knn2(self._m, q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0],
