@@ -335,19 +335,34 @@ def main():
             qa_h, ta_h = synth.synth_knn_adversarial(NQ, NT, seed=0xD35C)
             rate_adv = time_search(torch.from_numpy(qa_h[rank * nq_l:(rank + 1) * nq_l]).to(dev),
                                    torch.from_numpy(ta_h[nt0:nt1]).to(dev))
-            # Integer-issue bound of the scan: per pair 8 XOR (2.8 cycles per wave64 instruction per
+            # the same job on the vector ALU (xor + popcount), for the comparison the choice of path rests on
+            m.debug_knn_path(1)
+            rate_valu = time_search(q_l, t_l, reps=1)
+            m.debug_knn_path(0)
+            # Matrix-core roofline of the scan: a pair of 256-bit descriptors is a 256-long contraction =
+            # 512 operations in the block-scaled fp4 form (dense peak 10 PFLOP/s per GPU).  The rate the chip
+            # sustains on this operand mix with nothing but the matrix instruction in flight (0/1 x +-1
+            # nibbles, two waves per SIMD, tools/probe/mfma_probe.hip) is power-limited well below that peak.
+            PEAK_FP4 = 1.0e16
+            SUSTAINED = 15.35e12
+            # Integer-issue bound of the vector-ALU form: per pair 8 XOR (2.8 cycles per wave64 instruction per
             # SIMD, measured) + 8 popcount-accumulate (4.5 cycles), 1024 SIMDs at 2.4 GHz
             issue_bound = 1024 * 2.4e9 * 64 / (8 * 2.8 + 8 * 4.5)
             out["hamming"] = {"pairs_per_s": round(rate, 1), "nq": nq_l * world, "nt": NT,
                               "workload": "seed 0xD35C, 50% planted near-duplicates (<= 30 flips), ties at higher "
                                           "indices, k=2 + ratio test 0.6 / TH_LOW 50 inside the timed region",
+                              "path": "matrix cores: v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands 0/1 x +-1, exact",
                               "accepted_matches": accepted,
                               "pairs_per_s_falling_distances": round(rate_adv, 1),
-                              "int_ops_per_pair": 16,
-                              "issue_bound_pairs_per_s_per_gpu": round(issue_bound, 1),
-                              "frac_of_issue_bound": round(rate / (issue_bound * world), 4),
-                              "issue_bound_note": "8 v_xor at 2.8 + 8 v_bcnt at 4.5 cycles per 64 pairs per SIMD "
-                                                  "(profiles/r1_probes.txt), 1024 SIMDs at 2.4 GHz",
+                              "pairs_per_s_vector_alu": round(rate_valu, 1),
+                              "roofline": {"bound": "mfma", "achieved": round(rate * 512 / world / 1e12, 1),
+                                           "peak": PEAK_FP4 / 1e12, "unit": "TFLOP/s",
+                                           "frac": round(rate * 512 / world / PEAK_FP4, 4), "traffic": None},
+                              "sustained_matrix_rate_pairs_per_s_per_gpu": SUSTAINED,
+                              "frac_of_sustained_matrix_rate": round(rate / (SUSTAINED * world), 4),
+                              "sustained_note": "profiles/r2_mfma_probe.txt: fp4 32x32x64, 0/1 x +-1, 2 waves per SIMD, "
+                                                "operands in registers",
+                              "vector_alu_issue_bound_pairs_per_s_per_gpu": round(issue_bound, 1),
                               "exchange": ("all-gather queries + all-to-all partials (RCCL)" if torch.distributed.get_backend() == "nccl"
                                            else "all-gather queries + all-gather partials (gloo rehearsal)") if world > 1 else "none"}
             m.close()

@@ -2141,20 +2141,28 @@ __device__ __forceinline__ uint4 knn_nibbles(const u32* lut, const u32 w) {
     return make_uint4(lut[w & 0xFFu], lut[(w >> 8) & 0xFFu], lut[(w >> 16) & 0xFFu], lut[w >> 24]);
 }
 
+// The accumulators start at 2^23 + 256, so the f32 result 2^23 + 256 + <a, q> has the bit pattern
+// KNN_ACC0 + <a, q>: an unsigned integer that orders like the distance and whose low bits, shifted,
+// give the key without a conversion.
+#define KNN_ACC0 0x4B000100u
+__device__ __forceinline__ u32 f32_bits(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) { return min(min(a, b), c); }
+
 template <bool TAIL>
 __device__ __forceinline__ void knn_fold16(const v16f acc, const int pq, const int row0, const int nt, u32& best, u32& second,
-                                           float& thr) {
-    // key = distance << KNN_IDX_BITS | row with distance = popcount(query) + acc
-    const u32 k0 = ((u32)pq << KNN_IDX_BITS) + (u32)row0;
+                                           u32& thr) {
+    // key = distance << KNN_IDX_BITS | row, distance = popcount(query) + <a, q>; (bits << KNN_IDX_BITS) keeps
+    // only 256 + <a, q> of the pattern, so the constant carries popcount - 256
+    const u32 k0 = ((u32)(pq - 256) << KNN_IDX_BITS) + (u32)row0;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int off = (r & 3) + 8 * (r >> 2);
-        u32 key = ((u32)(int)acc[r] << KNN_IDX_BITS) + (k0 + (u32)off);
+        u32 key = (f32_bits(acc[r]) << KNN_IDX_BITS) + (k0 + (u32)off);
         if (TAIL) key = row0 + off < nt ? key : 0xFFFFFFFFu;
         second = umed3(best, second, key);
         best = min(best, key);
     }
-    thr = (float)((int)(second >> KNN_IDX_BITS) - pq);
+    thr = KNN_ACC0 + (second >> KNN_IDX_BITS) - (u32)pq;
 }
 
 __global__ __launch_bounds__(256) void k_knn2_mfma(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt,
@@ -2202,12 +2210,11 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint4* __restrict__ q, 
                              (int)(0x22222222u | (e.w << 2))};
         }
     }
-    u32 best[KNN_MQ], second[KNN_MQ];
-    float thr[KNN_MQ];
+    u32 best[KNN_MQ], second[KNN_MQ], thr[KNN_MQ];
 #pragma unroll
     for (int m = 0; m < KNN_MQ; m++) {
         best[m] = second[m] = 0xFFFFFFFFu;
-        thr[m] = 1e9f;
+        thr[m] = 0xFFFFFFFFu;  // a row can change a lane's two smallest only if its pattern is below this
     }
     // staging role of this thread: row sr of the stage, descriptor bytes 8 sp .. 8 sp + 7
     const int sr = threadIdx.x >> 2, sp = threadIdx.x & 3;
@@ -2223,40 +2230,69 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint4* __restrict__ q, 
     uint2 pre = t2[(i64)min(KNN_MROWS + sr, nt - 1) * 4 + sp];
     __syncthreads();
     const int unit = 0x7F7F7F7F;  // block scales 2^0
+    const float c0 = __uint_as_float(KNN_ACC0);
+    // sixteen registers that hold the constant for the whole scan (opaque to the compiler, which otherwise
+    // rebuilds the tuple with sixteen moves per tile)
+    v16f init = {c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0, c0};
+    asm volatile("" : "+v"(init));
+    constexpr int NT = (KNN_MROWS / 32) * KNN_MQ;  // result tiles per stage and wave
     for (int st = 0; st < nStages; st++) {
         const int buf = (st & 1) * (KNN_MROWS * KNN_MPITCH);
         // the next stage goes into the other buffer (last read before the barrier that ended the previous stage)
         if (st + 1 < nStages) stage(myDst + ((KNN_MROWS * KNN_MPITCH) - buf), pre);
         pre = t2[(i64)min((st + 2) * KNN_MROWS + sr, nt - 1) * 4 + sp];
         const bool tail = (st + 1) * KNN_MROWS > nt;
+        v4i At[KNN_MROWS / 32][4];
 #pragma unroll
-        for (int sub = 0; sub < KNN_MROWS / 32; sub++) {
-            v4i At[4];
+        for (int sub = 0; sub < KNN_MROWS / 32; sub++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) At[s] = *(const v4i*)(mySrc + buf + sub * 32 * KNN_MPITCH + s * 32);
-            // result register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 h of the sub-tile
-            const int row0 = st * KNN_MROWS + sub * 32 + 4 * h;
+            for (int s = 0; s < 4; s++) At[sub][s] = *(const v4i*)(mySrc + buf + sub * 32 * KNN_MPITCH + s * 32);
+        auto step = [&](const int j, const int s, const v16f cin) {
+            const v4i a = At[j / KNN_MQ][s], b = Bq[j % KNN_MQ][s];
+            const v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+            const v8i b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+            return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, cin, 4, 4, 0, unit, 0, unit);
+        };
+        // The four matrix instructions of tile j + 1 are issued between the pieces of the minimum over
+        // tile j's sixteen results, so the vector ALU works in the shadow of the matrix pipe.
+        v16f cur = step(0, 0, init);
 #pragma unroll
-            for (int m = 0; m < KNN_MQ; m++) {
-                v16f acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 1; s < 4; s++) cur = step(0, s, cur);
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const v8i a8 = {At[s][0], At[s][1], At[s][2], At[s][3], 0, 0, 0, 0};
-                    const v8i b8 = {Bq[m][s][0], Bq[m][s][1], Bq[m][s][2], Bq[m][s][3], 0, 0, 0, 0};
-                    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc, 4, 4, 0, unit, 0, unit);
-                }
-                // a row can change this lane's two smallest only if its distance is below the second one held
-                float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
+        for (int j = 0; j < NT; j++) {
+            const int m = j % KNN_MQ;
+            v16f nxt = init;
+            u32 mn;
+            if (j + 1 < NT) nxt = step(j + 1, 0, init);
+            mn = umin3(f32_bits(cur[0]), f32_bits(cur[1]), f32_bits(cur[2]));
+            mn = umin3(mn, f32_bits(cur[3]), f32_bits(cur[4]));
+            if (j + 1 < NT) nxt = step(j + 1, 1, nxt);
+            mn = umin3(mn, f32_bits(cur[5]), f32_bits(cur[6]));
+            mn = umin3(mn, f32_bits(cur[7]), f32_bits(cur[8]));
+            if (j + 1 < NT) nxt = step(j + 1, 2, nxt);
+            mn = umin3(mn, f32_bits(cur[9]), f32_bits(cur[10]));
+            mn = umin3(mn, f32_bits(cur[11]), f32_bits(cur[12]));
+            if (j + 1 < NT) nxt = step(j + 1, 3, nxt);
+            mn = umin3(mn, f32_bits(cur[13]), f32_bits(cur[14]));
+            mn = min(mn, f32_bits(cur[15]));
+            if (j + 1 < NT) {
+                // keeps tile j + 1's instructions on this side of the branch, one per two minimum steps
+                asm volatile("" : "+v"(nxt));
 #pragma unroll
-                for (int r = 3; r < 15; r += 2) mn = fminf(fminf(mn, acc[r]), acc[r + 1]);
-                mn = fminf(mn, acc[15]);
-                if (__any(mn < thr[m])) {
-                    if (tail)
-                        knn_fold16<true>(acc, pq[m], row0, nt, best[m], second[m], thr[m]);
-                    else
-                        knn_fold16<false>(acc, pq[m], row0, nt, best[m], second[m], thr[m]);
+                for (int k = 0; k < 4; k++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 }
             }
+            if (__any(mn < thr[m])) {
+                // result register r of a lane is train row (r & 3) + 8 (r >> 2) + 4 h of the sub-tile
+                const int row0 = st * KNN_MROWS + (j / KNN_MQ) * 32 + 4 * h;
+                if (tail)
+                    knn_fold16<true>(cur, pq[m], row0, nt, best[m], second[m], thr[m]);
+                else
+                    knn_fold16<false>(cur, pq[m], row0, nt, best[m], second[m], thr[m]);
+            }
+            cur = nxt;
         }
         __syncthreads();
     }
@@ -3777,6 +3813,34 @@ int orbm_unpack_keyframe_records(orbm_context* m, const uint8_t* records, int n,
     return ORBX_OK;
 }
 
+// How one 2-NN scan is laid out on the GPU.  Two forms of the same scan: on the matrix cores (an
+// exact fp4 contraction) when the problem is large enough to pay for the expansion of bits to
+// nibbles, on the vector ALU (xor + popcount) otherwise.  With too few queries to fill the GPU the
+// train rows are split over blockIdx.y (slices > 1) and the partials are folded in order;
+// maxPartEntries bounds slices * nq (the partial arrays' capacity), 0 = no bound.
+struct KnnPlan {
+    bool mfma;
+    int blocks, slices, sliceRows;
+};
+static KnnPlan knn_plan(int path, int nq, int nt, size_t maxPartEntries, bool alwaysSliced) {
+    KnnPlan p;
+    p.mfma = path == 2 || (path == 0 && nq >= 512 && nt >= 512 && (i64)nq * nt >= ((i64)1 << 24));
+    p.blocks = p.mfma ? (nq + 4 * 32 * KNN_MQ - 1) / (4 * 32 * KNN_MQ) : (nq + 256 * KNN_QPT - 1) / (256 * KNN_QPT);
+    const int rowQuantum = p.mfma ? KNN_MROWS : 8;
+    p.slices = 1;
+    if (p.blocks < (p.mfma ? 512 : 128) && nt >= 128 && nt <= (1 << KNN_IDX_BITS)) {
+        p.slices = std::min(nt / (p.mfma ? 2 * KNN_MROWS : 32), std::max((p.mfma ? 2048 : 1024) / p.blocks, 1));
+        if (maxPartEntries) p.slices = (int)std::min<size_t>((size_t)p.slices, maxPartEntries / (size_t)nq);
+        p.slices = std::max(p.slices, 1);
+    }
+    p.sliceRows = 0;
+    if (p.slices > 1 || alwaysSliced) {
+        p.sliceRows = std::max(((nt + p.slices - 1) / p.slices + rowQuantum - 1) / rowQuantum * rowQuantum, rowQuantum);
+        p.slices = std::max((nt + p.sliceRows - 1) / p.sliceRows, 1);
+    }
+    return p;
+}
+
 int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int train_index_base,
               int32_t* best_idx, int32_t* best_d, int32_t* second_d, int mem_space) {
     int rc = use_device(m);
@@ -3800,40 +3864,32 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
     if ((rc = stage_out(m, SL_KNN_D, (int*)best_d, (size_t)nq, mem_space, &dd))) return rc;
     if ((rc = stage_out(m, SL_KNN_S, (int*)second_d, (size_t)nq, mem_space, &ds))) return rc;
     const int chunkRows = 1 << KNN_IDX_BITS;
-    // Two forms of the same scan: on the matrix cores (an exact int8 contraction) when the problem is
-    // large enough to pay for the expansion of bits to bytes, on the vector ALU (xor + popcount) otherwise.
-    const bool mfma = m->knnPath == 2 || (m->knnPath == 0 && nq >= 512 && nt >= 512 && (i64)nq * nt >= ((i64)1 << 24));
-    const int blocks = mfma ? (nq + 4 * 32 * KNN_MQ - 1) / (4 * 32 * KNN_MQ) : (nq + 256 * KNN_QPT - 1) / (256 * KNN_QPT);
-    const int rowQuantum = mfma ? KNN_MROWS : 8;
-    if (blocks < (mfma ? 512 : 128) && nt >= 128 && nt <= chunkRows) {
-        // too few queries to fill the GPU: the train rows are split over blockIdx.y and the partials folded in order
-        int slices = std::min(nt / (mfma ? 2 * KNN_MROWS : 32), std::max((mfma ? 2048 : 1024) / blocks, 1));
-        slices = std::max(slices, 1);
-        const int sliceRows = ((nt + slices - 1) / slices + rowQuantum - 1) / rowQuantum * rowQuantum;
-        slices = (nt + sliceRows - 1) / sliceRows;
+    const KnnPlan p = knn_plan(m->knnPath, nq, nt, 0, false);
+    if (p.slices > 1) {
         void *pi, *pd, *ps;
-        const size_t partBytes = (size_t)slices * nq * sizeof(int);
+        const size_t partBytes = (size_t)p.slices * nq * sizeof(int);
         if ((rc = pool_get(m, SL_KNN_I2, partBytes, &pi)) || (rc = pool_get(m, SL_KNN_D2, partBytes, &pd)) ||
             (rc = pool_get(m, SL_KNN_S2, partBytes, &ps)))
             return rc;
-        if (mfma)
-            ORBM_LAUNCH(k_knn2_mfma, dim3(blocks, slices), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt, nt,
-                        train_index_base, (int*)pi, (int*)pd, (int*)ps, 0, sliceRows);
+        if (p.mfma)
+            ORBM_LAUNCH(k_knn2_mfma, dim3(p.blocks, p.slices), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt,
+                        nt, train_index_base, (int*)pi, (int*)pd, (int*)ps, 0, p.sliceRows);
         else
-            ORBM_LAUNCH(k_knn2, dim3(blocks, slices), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt, nt,
-                        train_index_base, (int*)pi, (int*)pd, (int*)ps, 0, sliceRows);
-        ORBM_LAUNCH(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, slices, (const int*)pi,
+            ORBM_LAUNCH(k_knn2, dim3(p.blocks, p.slices), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)dt, nt,
+                        train_index_base, (int*)pi, (int*)pd, (int*)ps, 0, p.sliceRows);
+        ORBM_LAUNCH(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, p.slices, (const int*)pi,
                     (const int*)pd, (const int*)ps, di, dd, ds);
     } else {
+        // whole train set per block; sets beyond the key's index bits go chunk by chunk, merged into the output
         int c0 = 0;
         do {
             const int rows = std::min(chunkRows, nt - c0);
-            if (mfma && rows > 0)
-                ORBM_LAUNCH(k_knn2_mfma, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq,
+            if (p.mfma && rows > 0)
+                ORBM_LAUNCH(k_knn2_mfma, dim3(p.blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq,
                             (const uint4*)(dt + (size_t)c0 * 32), rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0, 0);
             else
-                ORBM_LAUNCH(k_knn2, dim3(blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq, (const uint4*)(dt + (size_t)c0 * 32),
-                            rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0, 0);
+                ORBM_LAUNCH(k_knn2, dim3(p.blocks), dim3(256), 0, m->stream, (const uint4*)dq, nq,
+                            (const uint4*)(dt + (size_t)c0 * 32), rows, train_index_base + c0, di, dd, ds, c0 > 0 ? 1 : 0, 0);
             c0 += rows;
         } while (c0 < nt);
     }
@@ -3888,14 +3944,14 @@ int orbm_knn2_noalloc(orbm_context* m, const uint8_t* q, int nq, const uint8_t* 
         return ORBX_ERR_HIP;
     }
     int *pi = base, *pd = base + KNN_NA_MAX_PART, *ps = base + 2 * KNN_NA_MAX_PART;
-    const int blocks = (nq + 256 * KNN_QPT - 1) / (256 * KNN_QPT);
-    int slices = std::min(nt / 32, std::max(1024 / blocks, 1));
-    slices = std::max(std::min(slices, KNN_NA_MAX_PART / nq), 1);
-    const int sliceRows = std::max(((nt + slices - 1) / slices + 7) & ~7, 8);
-    slices = std::max((nt + sliceRows - 1) / sliceRows, 1);
-    hipLaunchKernelGGL(k_knn2, dim3(blocks, slices), dim3(256), 0, m->stream, (const uint4*)q, nq, (const uint4*)t, nt,
-                       train_index_base, pi, pd, ps, 0, sliceRows);
-    hipLaunchKernelGGL(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, slices, (const int*)pi,
+    const KnnPlan p = knn_plan(m->knnPath, nq, nt, KNN_NA_MAX_PART, true);
+    if (p.mfma && nt > 0)
+        hipLaunchKernelGGL(k_knn2_mfma, dim3(p.blocks, p.slices), dim3(256), 0, m->stream, (const uint4*)q, nq, (const uint4*)t,
+                           nt, train_index_base, pi, pd, ps, 0, p.sliceRows);
+    else
+        hipLaunchKernelGGL(k_knn2, dim3(p.blocks, p.slices), dim3(256), 0, m->stream, (const uint4*)q, nq, (const uint4*)t, nt,
+                           train_index_base, pi, pd, ps, 0, p.sliceRows);
+    hipLaunchKernelGGL(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, p.slices, (const int*)pi,
                        (const int*)pd, (const int*)ps, (int*)best_idx, (int*)best_d, (int*)second_d);
     ORBX_HIP_CHECK(hipGetLastError());
     return ORBX_OK;

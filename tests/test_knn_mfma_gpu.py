@@ -77,3 +77,21 @@ def test_sliced_and_whole_scans_agree_with_the_vector_form(matcher):
         outs.append([x.cpu().numpy() for x in o])
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_entry_point_without_allocations_takes_the_same_path(matcher, oracle):
+    import torch
+    from slam_amd import synth
+    dev = torch.device("cuda:0")
+    matcher.debug_knn_path(2)
+    for nq, nt in ((3000, 5000), (700, 901)):
+        q = synth.synth_descriptors(nq, 31 + nq)
+        t = synth.synth_descriptors(nt, 32 + nt)
+        tq, tt = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)
+        o = [torch.full((nq,), -7, dtype=torch.int32, device=dev) for _ in range(3)]
+        matcher.knn2_noalloc_device(tq, tt, *o, index_base=5)
+        torch.cuda.synchronize()
+        ri, rd, rs = oracle.knn2(q, t, threads=16)
+        assert np.array_equal(o[0].cpu().numpy(), ri + 5)
+        assert np.array_equal(o[1].cpu().numpy(), rd)
+        assert np.array_equal(o[2].cpu().numpy(), rs)
