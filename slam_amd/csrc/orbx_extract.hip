@@ -262,6 +262,182 @@ __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, 
     }
 }
 
+// The same walk with wave-uniform control: a wave owns a band of destination rows and 64 lanes of
+// column groups (4 destination pixels each) that share the band's geometry.  The source row, the
+// destination row, the row weights and every branch of the walk are then the same for all lanes:
+// they live in scalar registers, the row tables come through the scalar cache, and a row's address
+// is a buffer descriptor (scalar) + a scalar row offset + a per-lane 32-bit offset fixed at
+// start-up, so neither the loads nor the stores need address arithmetic.  The vector ALU is left
+// with the arithmetic: per source row one 8-byte load, 4 v_perm, 4 v_dot2, 4 shifts; per
+// destination row 8 v_mul_hi, the adds, shifts and the byte pack.
+//
+// The lane's taps lie within 8 bytes of its first tap, so one unaligned 8-byte load per source row
+// brings its whole window (the memory pipeline, not the ALU, bounds this kernel: three aligned word
+// loads per row cost a quarter more time than this one).  The window is pulled back from the
+// row's end so that it never reaches past the last pixel of the image.
+struct ResizeLane {
+    u32 sel[4], coef[4];
+    u32 offS, offD;
+};
+__device__ __forceinline__ ResizeLane resize_lane(const ResizeTap* __restrict__ xt, int gx, int dw, int sw, u32 srcLaneBase,
+                                                  u32 dstLaneBase) {
+    ResizeLane L;
+    const ResizeTap t0 = xt[min(4 * gx, dw - 1)];
+    const int start = min((int)t0.i0, sw - 8);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const ResizeTap t = xt[min(4 * gx + j, dw - 1)];
+        const u32 d0 = t.i0 - start, d1 = t.i1 - start;
+        // bytes: [tap0, 0, tap1, 0]; selector 12 yields a zero byte
+        L.sel[j] = d0 | (12u << 8) | (d1 << 16) | (12u << 24);
+        L.coef[j] = (u32)(u16)t.c0 | ((u32)(u16)t.c1 << 16);
+    }
+    L.offS = srcLaneBase + (u32)start;
+    L.offD = dstLaneBase + 4u * (u32)gx;
+    return L;
+}
+
+// One band: destination rows y0 .. y1 - 1.  Everything but L is wave-uniform.
+__device__ __forceinline__ void resize_walk(const ResizeLane& L, const __amdgpu_buffer_rsrc_t srcRs,
+                                            const __amdgpu_buffer_rsrc_t dstRs, int srcPitch, int dPitch, int sh,
+                                            const ResizeTap* __restrict__ yt, const ResizeTap* __restrict__ st, int y0, int y1) {
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    struct Group {
+        u32x2 raw[RESIZE_PF];
+        uint4 tab[RESIZE_PF];  // scalar: st[2 s], st[2 s + 1]
+    };
+    auto load_group = [&](Group& g, int s0) {
+#pragma unroll
+        for (int k = 0; k < RESIZE_PF; k++) {
+            const int sr = min(s0 + k, sh - 1);
+            g.raw[k] = __builtin_amdgcn_raw_buffer_load_b64(srcRs, (int)L.offS, sr * srcPitch, 0);
+            g.tab[k] = *(const uint4*)(st + 2 * sr);
+        }
+    };
+    // st[2 * s + e], e = 0, 1: the destination rows whose second tap is source row s, as
+    // {i0 = destination row or 0xFFFF, i1 = 1 when both taps are row s, c0, c1}
+    int s = yt[y0].i0;                // first source row of the band
+    const int sLast = yt[y1 - 1].i1;  // last one
+    u32 prev[4] = {0, 0, 0, 0}, cur[4];
+    auto run_group = [&](const Group& g, int s0) {
+#pragma unroll
+        for (int k = 0; k < RESIZE_PF; k++) {
+            const u32 W0 = g.raw[k][0], W1 = g.raw[k][1];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 pr = __builtin_amdgcn_perm(W1, W0, L.sel[j]);
+                // horizontal sum, already shifted right by 4 as the vertical step wants
+                cur[j] = __builtin_amdgcn_udot2(as_u16x2(pr), as_u16x2(L.coef[j]), 0u, false) >> 4;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const u32 w0 = e == 0 ? g.tab[k].x : g.tab[k].z, w1 = e == 0 ? g.tab[k].y : g.tab[k].w;
+                const int y = (int)(w0 & 0xffffu);
+                if (y >= y0 && y < y1 && s0 + k <= sLast) {  // scalar branch
+                    if ((w0 >> 16) != 0) {                   // both taps are this row (clamped border)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) prev[j] = cur[j];
+                        // keeps this a branch: as a select it would cost four instructions on every row
+                        asm volatile("" : "+v"(prev[0]), "+v"(prev[1]), "+v"(prev[2]), "+v"(prev[3]));
+                    }
+                    // weights are 0..2048 and the shifted sums < 2^15: (b * t) >> 16 = mulhi(b << 16, t)
+                    const u32 b0 = w1 << 16, b1 = w1 & 0xffff0000u;
+                    u32 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = (__umulhi(b0, prev[j]) + __umulhi(b1, cur[j]) + 2u) >> 2;
+                    const u32 out = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                    __builtin_amdgcn_raw_buffer_store_b32(out, dstRs, (int)L.offD, y * dPitch, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) prev[j] = cur[j];
+        }
+    };
+    // Two register sets used alternately: a set is refilled right after its rows have been consumed and
+    // is not touched again until the other set has been worked through.
+    Group ga, gb;
+    load_group(ga, s);
+    while (true) {
+        load_group(gb, s + RESIZE_PF);
+        run_group(ga, s);
+        s += RESIZE_PF;
+        if (s > sLast) break;
+        load_group(ga, s + RESIZE_PF);
+        run_group(gb, s);
+        s += RESIZE_PF;
+        if (s > sLast) break;
+    }
+}
+
+// One level for a batch: the four waves of a workgroup take four consecutive bands; a wave's lanes are
+// W column groups (blockIdx.z) x K = 64 / W consecutive frames (lane = frame slot * W + group), W chosen
+// per level so that few lanes hang over the row's end.
+__global__ __launch_bounds__(256) void k_resize_rows(ImgRef src, int sw, int sh, u8* dst, int dPitch, i64 dFrame, int dw,
+                                                     int dh, const ResizeTap* __restrict__ xt,
+                                                     const ResizeTap* __restrict__ yt,
+                                                     const ResizeTap* __restrict__ st, int bandRows, int logW, int nFrames) {
+    const int G = (dw + 3) >> 2;
+    const int lane = threadIdx.x & 63;
+    // the wave number, read from lane 0, is a scalar
+    const int band = (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (band * bandRows >= dh) return;
+    const int gx = ((int)blockIdx.z << logW) + (lane & ((1 << logW) - 1));
+    const int fk = lane >> logW;
+    const int f0 = (int)blockIdx.x * (64 >> logW);
+    if (gx >= G || f0 + fk >= nFrames) return;
+    const ResizeLane L = resize_lane(xt, gx, dw, sw, (u32)fk * (u32)src.frameStride, (u32)fk * (u32)dFrame);
+    const int K = 64 >> logW;
+    const __amdgpu_buffer_rsrc_t srcRs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(src.base + (i64)f0 * src.frameStride), 0, (int)((u32)K * (u32)src.frameStride), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dstRs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (i64)f0 * dFrame), 0, (int)((u32)K * (u32)dFrame), 0x00020000);
+    resize_walk(L, srcRs, dstRs, src.pitch, dPitch, sh, yt, st, band * bandRows, min(band * bandRows + bandRows, dh));
+}
+
+// The whole pyramid of one frame in one workgroup: frames are independent, so the levels of a frame
+// need no grid-wide ordering, only a workgroup barrier between a level and the next (the rows a wave
+// reads were stored by waves of its own workgroup, on its own compute unit, and were never loaded
+// before).  One launch instead of one per level: no launch gaps, no idle tail at the end of every
+// level (workgroups drift apart, so small levels of one frame overlap large levels of another),
+// and a level is read back while it is still in the caches.
+struct PyramidLevel {
+    int sw, sh, dw, dh, srcPitch, dstPitch, chunks;
+    u32 srcOff, dstOff;  // byte offsets of the two levels inside a frame of the pyramid buffer
+    const ResizeTap *xt, *yt, *st;
+};
+struct PyramidArgs {
+    PyramidLevel lv[ORBX_MAX_LEVELS];
+};
+#define PYR_WAVES 16
+__global__ __launch_bounds__(64 * PYR_WAVES, 8) void k_pyramid_frame(ImgRef img0, u8* pyr, i64 pyrFrameBytes, int imgBytes,
+                                                                     PyramidArgs args, int nlevels) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int f = blockIdx.x;
+    u8* const frame = pyr + (i64)f * pyrFrameBytes;
+    for (int l = 1; l < nlevels; l++) {
+        const PyramidLevel& A = args.lv[l];
+        const __amdgpu_buffer_rsrc_t srcRs =
+            l == 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)(img0.base + (i64)f * img0.frameStride), 0, imgBytes, 0x00020000)
+                   : __builtin_amdgcn_make_buffer_rsrc((void*)(frame + A.srcOff), 0, (int)(A.sh * A.srcPitch), 0x00020000);
+        const __amdgpu_buffer_rsrc_t dstRs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(frame + A.dstOff), 0, (int)(A.dh * A.dstPitch), 0x00020000);
+        // The waves are dealt to the chunks of 64 column groups (wave w -> chunk w % chunks), and the waves of
+        // a chunk split its rows into one contiguous band each: one start-up and one exposed load latency
+        // per wave and level, and bands that differ by at most a row.
+        const int G = (A.dw + 3) >> 2;
+        const int chunk = wave % A.chunks, idx = wave / A.chunks;
+        const int nw = (PYR_WAVES - chunk + A.chunks - 1) / A.chunks;  // waves on this chunk
+        const int y0 = (int)((i64)idx * A.dh / nw), y1 = (int)((i64)(idx + 1) * A.dh / nw);
+        const int gx = chunk * 64 + lane;
+        if (gx < G && y1 > y0) {
+            const ResizeLane L = resize_lane(A.xt, gx, A.dw, A.sw, 0u, 0u);
+            resize_walk(L, srcRs, dstRs, A.srcPitch, A.dstPitch, A.sh, A.yt, A.st, y0, y1);
+        }
+        __syncthreads();  // waits for this wave's stores, then for every wave of the frame
+    }
+}
+
 // ------------------------------------------------------------------ blur
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
@@ -1707,6 +1883,11 @@ struct orbx_handle {
     size_t tapsCap = 0;
     size_t tapXOff[ORBX_MAX_LEVELS], tapYOff[ORBX_MAX_LEVELS], tapSOff[ORBX_MAX_LEVELS];
     bool resizeStreamOk[ORBX_MAX_LEVELS];  // taps of a 4-pixel group fit the three-word window
+    PyramidArgs pyrArgs;                   // per-level arguments of the one-launch pyramid
+    bool pyrFrameOk = false;               // every level fits the one-launch pyramid's assumptions
+    int pyrFused = -1;                     // ORBX_PYR_FUSED: 1 / 0 forces the one-launch pyramid on / off (-1: by batch size)
+    int resizeLogW = 0;                    // ORBX_RESIZE_LOGW: forces the lane split of the wave-uniform form (measurement knob)
+    bool resizeRows = true;                // wave-uniform form of the streaming resize (ORBX_RESIZE_ROWS=0: per-lane form)
     // scratch sized for scratchBatch frames of the current geometry
     int scratchBatch = 0;
     size_t scratchSig = 0;
@@ -1868,6 +2049,9 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         L.pyrPitch = align_up(L.w, 64);
         L.blurPitch = align_up(L.w, 64);
         if (l > 0) {
+            // a level starts on a cache line of its own: the one-launch pyramid reads a level while the next
+            // one is being written, and a line holding bytes of both could be kept stale in the vector cache
+            pyrOff = (pyrOff + 255) & ~(i64)255;
             L.pyrOff = pyrOff;
             pyrOff += (i64)L.pyrPitch * L.h;
         }
@@ -1964,6 +2148,9 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         if (h->cfg.max_batch <= 4) h->qtThreads = 1024;
     }
     if (const char* e = getenv("ORBX_QT_THREADS")) h->qtThreads = atoi(e);
+    if (const char* e = getenv("ORBX_RESIZE_ROWS")) h->resizeRows = atoi(e) != 0;  // measurement knob
+    if (const char* e = getenv("ORBX_RESIZE_LOGW")) h->resizeLogW = atoi(e);
+    if (const char* e = getenv("ORBX_PYR_FUSED")) h->pyrFused = atoi(e);
     if (h->qtThreads != 256 && h->qtThreads != 512 && h->qtThreads != 1024) h->qtThreads = 256;
 
     // resize taps (cv::resize INTER_LINEAR, 8-bit, 11-bit fixed-point weights)
@@ -2063,6 +2250,25 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     if (!taps.empty()) {
         ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
         ORBX_HIP_CHECK(hipMemcpy(h->dTaps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    }
+    // arguments of the one-launch pyramid
+    h->pyrFrameOk = g.nlevels > 1 && g.pyrFrameBytes < 0x7FFFFFFFll;
+    memset(&h->pyrArgs, 0, sizeof(h->pyrArgs));
+    for (int l = 1; l < g.nlevels; l++) {
+        PyramidLevel& A = h->pyrArgs.lv[l];
+        A.sw = g.lv[l - 1].w;
+        A.sh = g.lv[l - 1].h;
+        A.dw = g.lv[l].w;
+        A.dh = g.lv[l].h;
+        A.srcPitch = l > 1 ? g.lv[l - 1].pyrPitch : 0;  // level 0 is the caller's image: filled in at launch
+        A.dstPitch = g.lv[l].pyrPitch;
+        A.srcOff = l > 1 ? (u32)g.lv[l - 1].pyrOff : 0u;
+        A.dstOff = (u32)g.lv[l].pyrOff;
+        A.chunks = ((A.dw + 3) / 4 + 63) / 64;
+        A.xt = h->dTaps + h->tapXOff[l];
+        A.yt = h->dTaps + h->tapYOff[l];
+        A.st = h->dTaps + h->tapSOff[l];
+        if (!h->resizeStreamOk[l] || A.sw < 8 || A.chunks > PYR_WAVES || (i64)A.sh * std::max(A.srcPitch, 1) > 0x7FFFFFFFll) h->pyrFrameOk = false;
     }
     // FAST cell records (reference src/ORBextractor.cc:799-817 for the ROI bounds)
     std::vector<FastCell> cells((size_t)g.totalCells);
@@ -2217,7 +2423,17 @@ int forced_band_rows(int level) {
 int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc, int cap, int* dN) {
     const Geom& g = h->g;
     hipStream_t st = h->stream;
-    {
+    // the one-launch pyramid wants a workgroup per frame on most compute units; small batches go level by level
+    const i64 imgBytes0 = (i64)(g.h - 1) * img0.pitch + g.w;
+    const bool fusedPyramid = h->pyrFrameOk && h->resizeRows && imgBytes0 <= 0x7FFFFFFFll &&
+                              (h->pyrFused >= 0 ? h->pyrFused != 0 : n >= 128);
+    if (fusedPyramid) {
+        StageTimer t(h, ORBX_STAGE_PYRAMID);
+        PyramidArgs args = h->pyrArgs;
+        args.lv[1].srcPitch = img0.pitch;
+        hipLaunchKernelGGL(k_pyramid_frame, dim3(n), dim3(64 * PYR_WAVES), 0, st, img0, h->dPyr, g.pyrFrameBytes, (int)imgBytes0, args,
+                           g.nlevels);
+    } else {
         StageTimer t(h, ORBX_STAGE_PYRAMID);
         for (int l = 1; l < g.nlevels; l++) {
             ImgRef src = img0;
@@ -2238,11 +2454,35 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
                     const int forced = forced_band_rows(l);  // measurement knob
                     if (forced > 0) bandRows = forced;
                 }
-                const int items = ((L.w + 3) / 4) * ((L.h + bandRows - 1) / bandRows);
-                dim3 grid(n, (items + 255) / 256, 1), block(256, 1, 1);
-                hipLaunchKernelGGL(k_resize_stream, grid, block, 0, st, src, src.pitch / 4 - 1, g.lv[l - 1].h, h->dPyr + L.pyrOff,
-                                   L.pyrPitch, g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l],
-                                   h->dTaps + h->tapYOff[l], h->dTaps + h->tapSOff[l], bandRows);
+                const int G = (L.w + 3) / 4, nb = (L.h + bandRows - 1) / bandRows;
+                // frames of 3 x the pyramid or image stride must fit the kernel's 32-bit lane offsets
+                const bool rowsOk = h->resizeRows && (u64)src.frameStride * 64 < 0xFFFFFFFFull && (u64)g.pyrFrameBytes * 64 < 0xFFFFFFFFull &&
+                                    nb <= 65535 && g.lv[l - 1].w >= 8;
+                if (rowsOk) {
+                    // lanes = W column groups x 64 / W frames: the W (>= 8) that wastes the fewest lanes, wider on ties
+                    int logW = 6;
+                    double bestEff = 0;
+                    for (int lw = 6; lw >= 3; lw--) {
+                        const int Wd = 1 << lw, K = 64 >> lw;
+                        const double eff = (double)G * n / ((double)((G + Wd - 1) / Wd) * Wd * ((n + K - 1) / K) * K);
+                        if (eff > bestEff + 1e-9) {
+                            bestEff = eff;
+                            logW = lw;
+                        }
+                    }
+                    if (h->resizeLogW >= 3 && h->resizeLogW <= 6) logW = h->resizeLogW;
+                    const int Wd = 1 << logW, K = 64 >> logW;
+                    dim3 grid((n + K - 1) / K, (nb + 3) / 4, (G + Wd - 1) / Wd), block(256, 1, 1);
+                    hipLaunchKernelGGL(k_resize_rows, grid, block, 0, st, src, g.lv[l - 1].w, g.lv[l - 1].h, h->dPyr + L.pyrOff,
+                                       L.pyrPitch, g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l],
+                                       h->dTaps + h->tapYOff[l], h->dTaps + h->tapSOff[l], bandRows, logW, n);
+                } else {
+                    const int items = G * nb;
+                    dim3 grid(n, (items + 255) / 256, 1), block(256, 1, 1);
+                    hipLaunchKernelGGL(k_resize_stream, grid, block, 0, st, src, src.pitch / 4 - 1, g.lv[l - 1].h,
+                                       h->dPyr + L.pyrOff, L.pyrPitch, g.pyrFrameBytes, L.w, L.h, h->dTaps + h->tapXOff[l],
+                                       h->dTaps + h->tapYOff[l], h->dTaps + h->tapSOff[l], bandRows);
+                }
             } else {
                 dim3 grid((L.w + 255) / 256, (L.h + 3) / 4, n), block(64, 4, 1);
                 hipLaunchKernelGGL(k_resize, grid, block, 0, st, src, h->dPyr + L.pyrOff, L.pyrPitch,
