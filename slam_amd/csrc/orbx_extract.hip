@@ -319,6 +319,8 @@ __device__ __forceinline__ void resize_walk(const ResizeLane& L, const __amdgpu_
     int s = yt[y0].i0;                // first source row of the band
     const int sLast = yt[y1 - 1].i1;  // last one
     u32 prev[4] = {0, 0, 0, 0}, cur[4];
+    u32 two = 2;
+    asm volatile("" : "+v"(two));  // a vector register for the byte-inserting shifts below
     auto run_group = [&](const Group& g, int s0) {
 #pragma unroll
         for (int k = 0; k < RESIZE_PF; k++) {
@@ -344,8 +346,18 @@ __device__ __forceinline__ void resize_walk(const ResizeLane& L, const __amdgpu_
                     const u32 b0 = w1 << 16, b1 = w1 & 0xffff0000u;
                     u32 v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] = (__umulhi(b0, prev[j]) + __umulhi(b1, cur[j]) + 2u) >> 2;
-                    const u32 out = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                    for (int j = 0; j < 4; j++) v[j] = __umulhi(b0, prev[j]) + __umulhi(b1, cur[j]) + 2u;
+                    // (v >> 2) <= 255: pixels 1..3 are shifted straight into their byte of the output word
+                    u32 out = v[0] >> 2;
+                    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                        : "+v"(out)
+                        : "v"(two), "v"(v[1]));
+                    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                        : "+v"(out)
+                        : "v"(two), "v"(v[2]));
+                    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                        : "+v"(out)
+                        : "v"(two), "v"(v[3]));
                     __builtin_amdgcn_raw_buffer_store_b32(out, dstRs, (int)L.offD, y * dPitch, 0);
                 }
             }
@@ -415,6 +427,15 @@ __global__ __launch_bounds__(64 * PYR_WAVES, 8) void k_pyramid_frame(ImgRef img0
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int f = blockIdx.x;
     u8* const frame = pyr + (i64)f * pyrFrameBytes;
+    // a wave's place in level l: chunk of 64 column groups (wave w -> chunk w % chunks) and, among the waves of
+    // that chunk, one contiguous band of rows: one start-up and one exposed load latency per wave and
+    // level, and bands that differ by at most a row
+    auto lane_setup = [&](int l) {
+        const PyramidLevel& A = args.lv[l];
+        const int gx = (wave % A.chunks) * 64 + lane;
+        return resize_lane(A.xt, min(gx, ((A.dw + 3) >> 2) - 1), A.dw, A.sw, 0u, 0u);
+    };
+    ResizeLane L = lane_setup(1);
     for (int l = 1; l < nlevels; l++) {
         const PyramidLevel& A = args.lv[l];
         const __amdgpu_buffer_rsrc_t srcRs =
@@ -422,18 +443,13 @@ __global__ __launch_bounds__(64 * PYR_WAVES, 8) void k_pyramid_frame(ImgRef img0
                    : __builtin_amdgcn_make_buffer_rsrc((void*)(frame + A.srcOff), 0, (int)(A.sh * A.srcPitch), 0x00020000);
         const __amdgpu_buffer_rsrc_t dstRs =
             __builtin_amdgcn_make_buffer_rsrc((void*)(frame + A.dstOff), 0, (int)(A.dh * A.dstPitch), 0x00020000);
-        // The waves are dealt to the chunks of 64 column groups (wave w -> chunk w % chunks), and the waves of
-        // a chunk split its rows into one contiguous band each: one start-up and one exposed load latency
-        // per wave and level, and bands that differ by at most a row.
         const int G = (A.dw + 3) >> 2;
         const int chunk = wave % A.chunks, idx = wave / A.chunks;
         const int nw = (PYR_WAVES - chunk + A.chunks - 1) / A.chunks;  // waves on this chunk
         const int y0 = (int)((i64)idx * A.dh / nw), y1 = (int)((i64)(idx + 1) * A.dh / nw);
-        const int gx = chunk * 64 + lane;
-        if (gx < G && y1 > y0) {
-            const ResizeLane L = resize_lane(A.xt, gx, A.dw, A.sw, 0u, 0u);
-            resize_walk(L, srcRs, dstRs, A.srcPitch, A.dstPitch, A.sh, A.yt, A.st, y0, y1);
-        }
+        if (chunk * 64 + lane < G && y1 > y0) resize_walk(L, srcRs, dstRs, A.srcPitch, A.dstPitch, A.sh, A.yt, A.st, y0, y1);
+        // the next level's column taps do not depend on this level's pixels: fetched while the frame's other waves finish
+        if (l + 1 < nlevels) L = lane_setup(l + 1);
         __syncthreads();  // waits for this wave's stores, then for every wave of the frame
     }
 }
