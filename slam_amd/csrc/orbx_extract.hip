@@ -31,7 +31,7 @@ typedef uint32_t u32;
 typedef unsigned long long u64;
 typedef long long i64;
 
-const int ORBX_PIPES = 3;
+const int ORBX_PIPES = 4;
 const int EDGE_THRESHOLD = 19;  // reference src/ORBextractor.cc:53
 const int MIN_BORDER = EDGE_THRESHOLD - 3;
 const int MAX_CELL = 59;  // largest cell side: ceil(width / floor(width/30)) < 60
@@ -1902,6 +1902,9 @@ struct orbx_handle {
     PyramidArgs pyrArgs;                   // per-level arguments of the one-launch pyramid
     bool pyrFrameOk = false;               // every level fits the one-launch pyramid's assumptions
     int pyrFused = -1;                     // ORBX_PYR_FUSED: 1 / 0 forces the one-launch pyramid on / off (-1: by batch size)
+    int maxPipes = 3;                      // ORBX_NPIPES: passes in flight (measurement knob)
+    bool forkBlur = true;                  // ORBX_FORK_BLUR=0: the blur stays on the pass's own stream
+    int blurLds = 0;                       // ORBX_BLUR_LDS: unused LDS bytes per blur workgroup, caps its share of a compute unit (measurement knob)
     int resizeLogW = 0;                    // ORBX_RESIZE_LOGW: forces the lane split of the wave-uniform form (measurement knob)
     bool resizeRows = true;                // wave-uniform form of the streaming resize (ORBX_RESIZE_ROWS=0: per-lane form)
     // scratch sized for scratchBatch frames of the current geometry
@@ -2167,6 +2170,9 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     if (const char* e = getenv("ORBX_RESIZE_ROWS")) h->resizeRows = atoi(e) != 0;  // measurement knob
     if (const char* e = getenv("ORBX_RESIZE_LOGW")) h->resizeLogW = atoi(e);
     if (const char* e = getenv("ORBX_PYR_FUSED")) h->pyrFused = atoi(e);
+    if (const char* e = getenv("ORBX_NPIPES")) h->maxPipes = std::min(std::max(atoi(e), 1), ORBX_PIPES);
+    if (const char* e = getenv("ORBX_FORK_BLUR")) h->forkBlur = atoi(e) != 0;
+    if (const char* e = getenv("ORBX_BLUR_LDS")) h->blurLds = std::min(std::max(atoi(e), 0), 65536);
     if (h->qtThreads != 256 && h->qtThreads != 512 && h->qtThreads != 1024) h->qtThreads = 256;
 
     // resize taps (cv::resize INTER_LINEAR, 8-bit, 11-bit fixed-point weights)
@@ -2506,7 +2512,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             }
         }
     }
-    const bool fork = h->overlapBlur && h->auxStream != nullptr;
+    const bool fork = h->overlapBlur && h->forkBlur && h->auxStream != nullptr;
     hipStream_t bst = fork ? h->auxStream : st;
     if (fork) {
         ORBX_HIP_CHECK(hipEventRecord(h->evPyramid, st));
@@ -2537,7 +2543,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             for (int l = first; l < g.nlevels; l++) gs.lv[l].blurItemBase -= itemBegin;
             dim3 grid(n, (g.totalBlurItems - itemBegin + 255) / 256, 1), block(256, 1, 1);
             auto kb = h->cfg.blur_variant == 2 ? k_blur_stream<true> : k_blur_stream<false>;
-            hipLaunchKernelGGL(kb, grid, block, 0, bst, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+            hipLaunchKernelGGL(kb, grid, block, h->blurLds, bst, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
                                h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
         }
     }
@@ -2754,7 +2760,7 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
     if (rc) return rc;
     const int chunk = std::min(B, h->cfg.max_batch);
     const int npass = (B + chunk - 1) / chunk;
-    const int npipes = (mem_space == ORBX_MEM_DEVICE && h->overlapBlur) ? std::min(ORBX_PIPES, npass) : 1;
+    const int npipes = (mem_space == ORBX_MEM_DEVICE && h->overlapBlur) ? std::min(std::min(ORBX_PIPES, h->maxPipes), npass) : 1;
     rc = ensure_scratch(h, chunk * npipes);
     if (rc) return rc;
     select_scratch(h, 0);
