@@ -35,7 +35,7 @@ ALG_BYTES = {
     "describe": NFEAT * (749 + 512 + 60),               # patch + test gathers + outputs per keypoint
     "quadtree": None,                                   # latency-bound list logic; bytes are negligible
 }
-KERNEL_OF = {"pyramid": "k_resize_stream (7 launches)", "fast": "k_fast", "quadtree": "k_quadtree",
+KERNEL_OF = {"pyramid": "k_pyramid_frame", "fast": "k_fast", "quadtree": "k_quadtree",
              "blur": "k_blur_stream", "describe": "k_describe"}
 
 
