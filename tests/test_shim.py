@@ -240,3 +240,43 @@ def test_reference_call_sites_match_oracle(tmp_path, oracle, sensor, tz):
     assert head[3] == n3 and n3 > 100 and np.array_equal(ini, m12)
     assert np.array_equal(prev.view(np.uint32), pm.view(np.uint32).reshape(-1, 2))
     assert head[4] == oracle.hamming256(db[0], da[1])
+
+
+# ---- the ORBX_WITH_OPENCV branch of the shim.  This image has no OpenCV: the branch is compiled against
+# tests/cpp/opencv_api_subset, a declaration-compatible subset of cv::Mat / cv::KeyPoint /
+# cv::InputArray / cv::OutputArray, so what is checked is that the branch is valid C++ against those
+# signatures and moves the right bytes; a build against a real OpenCV remains to be done by whoever has one.
+OCV_SRC = os.path.join(ROOT, "tests", "cpp", "opencv_branch_check.cpp")
+OCV_INC = os.path.join(ROOT, "tests", "cpp", "opencv_api_subset")
+
+
+def build_opencv_branch(tmp_path):
+    exe = os.path.join(str(tmp_path), "opencv_branch_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + OCV_INC, "-o", exe, OCV_SRC, "-L" + LIBDIR,
+                           "-lorbx", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    return exe
+
+
+def test_opencv_branch_of_the_shim_compiles(tmp_path):
+    build_opencv_branch(tmp_path)
+
+
+@pytest.mark.gpu
+def test_opencv_branch_of_the_shim_matches_ctypes(tmp_path, extractor_vga):
+    from slam_amd._lib import KP_DTYPE
+    exe = build_opencv_branch(tmp_path)
+    img = synth.synth_image(640, 480, 23)
+    raw = os.path.join(str(tmp_path), "i.raw")
+    out = os.path.join(str(tmp_path), "o.bin")
+    img.tofile(raw)
+    subprocess.check_call([exe, raw, "640", "480", out])
+    blob = open(out, "rb").read()
+    n = int(np.frombuffer(blob[:4], np.int32)[0])
+    kps = np.frombuffer(blob[4:4 + 28 * n], KP_DTYPE)
+    desc = np.frombuffer(blob[4 + 28 * n:4 + 60 * n], np.uint8).reshape(n, 32)
+    k2, d2 = extractor_vga(img, None)
+    assert n == len(k2) and n > 900 and np.array_equal(kps, k2) and np.array_equal(desc, d2)
+    rows, cols = np.frombuffer(blob[4 + 60 * n:12 + 60 * n], np.int32)
+    lvl = np.frombuffer(blob[12 + 60 * n:12 + 60 * n + rows * cols], np.uint8).reshape(rows, cols)
+    assert np.array_equal(lvl, extractor_vga.image_pyramid_level(0, 2))
+    assert int(np.frombuffer(blob[12 + 60 * n + rows * cols:16 + 60 * n + rows * cols], np.int32)[0]) == 1
