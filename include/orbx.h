@@ -435,6 +435,26 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
                                     const float* scale_factors, int nlevels, float bf, float th,
                                     int check_orientation);
 
+/* Many independent projected searches in one call: orbm_search_projected for every entry of `jobs`
+ * under one policy, i.e. the batched form of the three SearchByProjection overloads that project map
+ * points into a frame or keyframe (reference src/ORBmatcher.cc:62-164, :370-485, :1694-1836; the
+ * frame-to-frame overload has orbm_search_by_projection_batch).  Every array a job points to is
+ * DEVICE memory (the job table itself is host memory); claimed / claimed_obs are in/out per job,
+ * query_best may be NULL, nmatches is written on return.  window_hint: an upper bound of the window
+ * half-sizes (q.radius) if the caller knows one, 0 otherwise; it only selects how many queries share a
+ * wave in the window walk (<= 8 and <= 15 pixels have forms of their own) and never changes a result. */
+typedef struct orbm_projected_job {
+    orbm_frame train;
+    const float* train_u_right; /* train.n, or NULL */
+    orbm_proj_queries q;
+    int32_t* claimed;           /* train.n, in/out */
+    uint8_t* claimed_obs;       /* train.n, in/out */
+    int32_t* query_best;        /* q.n or NULL */
+    int32_t nmatches;           /* out */
+} orbm_projected_job;
+int orbm_search_projected_batch(orbm_context* m, orbm_projected_job* jobs, int njobs,
+                                const orbm_proj_policy* p, float window_hint);
+
 /* Brute-force 2-nearest-neighbour search over 256-bit descriptors with the
  * serial-scan semantics of the reference's descriptor loops
  * (src/ORBmatcher.cc:255-282): best = smallest distance, lowest train index on

@@ -61,6 +61,11 @@ class ProjectionPair(C.Structure):
                 ("query_best", C.c_void_p), ("nmatches", C.c_int32)]
 
 
+class ProjectedJob(C.Structure):
+    _fields_ = [("train", MFrame), ("train_u_right", C.c_void_p), ("q", ProjQueries), ("claimed", C.c_void_p),
+                ("claimed_obs", C.c_void_p), ("query_best", C.c_void_p), ("nmatches", C.c_int32)]
+
+
 class Vocabulary(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("n_children", C.c_int32), ("levels", C.c_int32), ("node_desc", C.c_void_p),
                 ("child_start", C.c_void_p), ("children", C.c_void_p), ("word_id", C.c_void_p), ("weight", C.c_void_p)]
@@ -136,6 +141,7 @@ SIGNATURES = {
     "orbm_compute_stereo_matches": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), C.POINTER(Pyramid),
                                          C.POINTER(Pyramid), _vp, _vp, _f, _f, _vp, _vp, _vp, _i]),
     "orbm_search_by_projection_batch": (_i, [_vp, C.POINTER(ProjectionPair), _i, _vp, _i, _f, _f, _i]),
+    "orbm_search_projected_batch": (_i, [_vp, C.POINTER(ProjectedJob), _i, C.POINTER(ProjPolicy), _f]),
     "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
     "orbm_bow_transform": (_i, [_vp, C.POINTER(Vocabulary), _vp, _i, _i, _vp, _vp, _vp, _i]),
     "orbm_ratio_test": (_i, [_vp, _i, _vp, _vp, _f, _i, _vp, _i]),

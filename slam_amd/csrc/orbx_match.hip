@@ -3143,6 +3143,91 @@ int orbm_search_by_projection(orbm_context* m, const orbm_frame* cur, const orbm
     return run_projected(m, dc, dUR, dq, pol, cur_claimed, cur_claimed_obs, query_best, nmatches, mem_space);
 }
 
+// The launches of a table of projected-search jobs (one job per frame pair or per (frame, point set)):
+// grids, the frame-to-frame query set-up when m4, one walk of every window into the per-query slots, and
+// the claim resolution from LDS; the two-walk CSR route when a slot overflowed or a job exceeds the LDS.
+// `th` only selects the form of the window walk (queries per wave).  On return m->totalsHost[i] is job i's
+// number of matches.
+static int run_projection_jobs(orbm_context* m, ProjJob* jobs, void* dJobs, int npairs, int maxNl, ProjPolicy pol, bool m4,
+                               const void* dSf, float bf, float th, void* dTot, int* dOverflow, int* nmArr) {
+    int rc;
+    const size_t jobBytes = (size_t)npairs * sizeof(ProjJob);
+    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
+    const ProjJob* dJ = (const ProjJob*)dJobs;
+    ORBM_LAUNCH(k_grid_build_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ);
+    // windows of a few grid cells (radius th * scale factor of the level) go four queries to a wave
+    const bool smallWindows = th <= 15.f;
+    auto launch_candidates = [&](int mode) {
+        if (th <= 8.f)
+            ORBM_LAUNCH(k_projq_candidates_jobs_sub<8>, dim3((maxNl + 31) / 32, npairs), dim3(256), 0, m->stream, dJ, mode);
+        else if (smallWindows)
+            ORBM_LAUNCH(k_projq_candidates_jobs_sub<16>, dim3((maxNl + 15) / 16, npairs), dim3(256), 0, m->stream, dJ, mode);
+        else
+            ORBM_LAUNCH(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, mode);
+    };
+    if (maxNl > 0) {
+        if (m4)
+            ORBM_LAUNCH(k_m4_queries_jobs, dim3((maxNl + 255) / 256, npairs), dim3(256), 0, m->stream, dJ, (const float*)dSf, bf,
+                        th);
+        launch_candidates(3);
+    }
+    ORBM_LAUNCH(k_scan_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ, (int*)dTot);
+    ORBX_HIP_CHECK(hipGetLastError());
+    m->totalsHost.resize((size_t)npairs);
+    int overflow = 0;
+    if ((rc = d2h(m, m->totalsHost.data(), dTot, (size_t)npairs * sizeof(int))) || (rc = d2h(m, &overflow, dOverflow, sizeof(int))))
+        return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
+    size_t maxLds = 0;
+    bool fits = true;
+    for (int i = 0; i < npairs; i++) {
+        const size_t tot = (size_t)m->totalsHost[i], nq = (size_t)jobs[i].q.n, nt = (size_t)jobs[i].train.n;
+        maxLds = std::max(maxLds, tot * 4 + (nq + 1) * 4 + nt * (8 + (pol.ratioTest ? 4 : 0) + 2) + nq + 16);
+        fits = fits && tot < 65536 && nt <= 65536;
+    }
+    fits = fits && maxLds <= 150 * 1024;
+    if (fits && !m->resolveJobsLdsReady) {
+        ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds_jobs<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds_jobs<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        m->resolveJobsLdsReady = true;
+    }
+    auto resolve_lds = [&](int fromSlab) {
+        if (pol.ratioTest)
+            ORBM_LAUNCH(k_projq_resolve_lds_jobs<true>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, fromSlab);
+        else
+            ORBM_LAUNCH(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, fromSlab);
+    };
+    const bool oneWalk = fits && !overflow;
+    if (oneWalk) {
+        resolve_lds(1);
+    } else {
+    size_t total = 0;
+    for (int i = 0; i < npairs; i++) total += (size_t)m->totalsHost[i];
+    void *cIdx, *cDist;
+    if ((rc = pool_get(m, SL_CAND_IDX, std::max(total, (size_t)1) * 4, &cIdx)) ||
+        (rc = pool_get(m, SL_CAND_DIST, std::max(total, (size_t)1) * 4, &cDist)))
+        return rc;
+    size_t off = 0;
+    for (int i = 0; i < npairs; i++) {
+        jobs[i].candIdx = (int*)cIdx + off;
+        jobs[i].candDist = (int*)cDist + off;
+        off += (size_t)m->totalsHost[i];
+    }
+    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
+    if (maxNl > 0) launch_candidates(2);
+    if (fits)
+        resolve_lds(0);
+    else
+        ORBM_LAUNCH(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
+    }
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = d2h(m, m->totalsHost.data(), nmArr, (size_t)npairs * sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
+    return ORBX_OK;
+}
+
 int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs, int npairs, const float* scale_factors,
                                     int nlevels, float bf, float th, int check_orientation) {
     int rc = use_device(m);
@@ -3247,73 +3332,104 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
         J.q.uRight = J.qUR;
         J.q.rightGate = J.qRadius;  // er > radius rejects (reference src/ORBmatcher.cc:1619)
     }
-    const size_t jobBytes = (size_t)npairs * sizeof(ProjJob);
-    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
-    const ProjJob* dJ = (const ProjJob*)dJobs;
-    ORBM_LAUNCH(k_grid_build_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ);
-    // windows of a few grid cells (radius th * scale factor of the level) go four queries to a wave
-    const bool smallWindows = th <= 15.f;
-    auto launch_candidates = [&](int mode) {
-        if (th <= 8.f)
-            ORBM_LAUNCH(k_projq_candidates_jobs_sub<8>, dim3((maxNl + 31) / 32, npairs), dim3(256), 0, m->stream, dJ, mode);
-        else if (smallWindows)
-            ORBM_LAUNCH(k_projq_candidates_jobs_sub<16>, dim3((maxNl + 15) / 16, npairs), dim3(256), 0, m->stream, dJ, mode);
-        else
-            ORBM_LAUNCH(k_projq_candidates_jobs, dim3((maxNl + 3) / 4, npairs), dim3(256), 0, m->stream, dJ, mode);
-    };
-    if (maxNl > 0) {
-        ORBM_LAUNCH(k_m4_queries_jobs, dim3((maxNl + 255) / 256, npairs), dim3(256), 0, m->stream, dJ, (const float*)dSf, bf,
-                           th);
-        launch_candidates(3);
-    }
-    ORBM_LAUNCH(k_scan_jobs, dim3(npairs), dim3(1024), 0, m->stream, dJ, (int*)dTot);
-    ORBX_HIP_CHECK(hipGetLastError());
-    m->totalsHost.resize((size_t)npairs);
-    int overflow = 0;
-    if ((rc = d2h(m, m->totalsHost.data(), dTot, (size_t)npairs * sizeof(int))) || (rc = d2h(m, &overflow, dOverflow, sizeof(int))))
-        return rc;
-    ORBX_HIP_CHECK(sync_deliver(m));
     ProjPolicy pol = {0, TH_HIGH, 0, 0.f, check_orientation};
-    size_t maxLds = 0;
-    bool fits = true;
-    for (int i = 0; i < npairs; i++) {
-        const size_t tot = (size_t)m->totalsHost[i], nq = (size_t)pairs[i].last.n, nt = (size_t)pairs[i].cur.n;
-        maxLds = std::max(maxLds, tot * 4 + (nq + 1) * 4 + nt * 10 + nq + 16);
-        fits = fits && tot < 65536 && nt <= 65536;
-    }
-    fits = fits && maxLds <= 150 * 1024;
-    if (fits && !m->resolveJobsLdsReady) {
-        ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_projq_resolve_lds_jobs<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        m->resolveJobsLdsReady = true;
-    }
-    const bool oneWalk = fits && !overflow;
-    if (oneWalk) {
-        ORBM_LAUNCH(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, 1);
-    } else {
-    size_t total = 0;
-    for (int i = 0; i < npairs; i++) total += (size_t)m->totalsHost[i];
-    void *cIdx, *cDist;
-    if ((rc = pool_get(m, SL_CAND_IDX, std::max(total, (size_t)1) * 4, &cIdx)) ||
-        (rc = pool_get(m, SL_CAND_DIST, std::max(total, (size_t)1) * 4, &cDist)))
-        return rc;
-    size_t off = 0;
-    for (int i = 0; i < npairs; i++) {
-        jobs[i].candIdx = (int*)cIdx + off;
-        jobs[i].candDist = (int*)cDist + off;
-        off += (size_t)m->totalsHost[i];
-    }
-    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
-    if (maxNl > 0) launch_candidates(2);
-    if (fits)
-        ORBM_LAUNCH(k_projq_resolve_lds_jobs<false>, dim3(npairs), dim3(256), maxLds, m->stream, dJ, pol, 0);
-    else
-        ORBM_LAUNCH(k_projq_resolve_jobs, dim3(npairs), dim3(64), 0, m->stream, dJ, pol);
-    }
-    ORBX_HIP_CHECK(hipGetLastError());
-    if ((rc = d2h(m, m->totalsHost.data(), nmArr, (size_t)npairs * sizeof(int)))) return rc;
-    ORBX_HIP_CHECK(sync_deliver(m));
+    if ((rc = run_projection_jobs(m, jobs, dJobs, npairs, maxNl, pol, true, dSf, bf, th, dTot, dOverflow, nmArr))) return rc;
     for (int i = 0; i < npairs; i++) pairs[i].nmatches = m->totalsHost[i];
+    return ORBX_OK;
+}
+
+int orbm_search_projected_batch(orbm_context* m, orbm_projected_job* jobsIn, int njobs, const orbm_proj_policy* p,
+                                float window_hint) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (njobs < 0 || (njobs > 0 && !jobsIn) || !p) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (njobs == 0) return ORBX_OK;
+    size_t words = 0, bytes = 0;
+    int maxNq = 0;
+    for (int i = 0; i < njobs; i++) {
+        const orbm_projected_job& P = jobsIn[i];
+        const orbm_proj_queries& Q = P.q;
+        if (P.train.n < 0 || Q.n < 0 || P.train.n > 65000 || Q.n > 65000 ||
+            (Q.n > 0 && (!Q.valid || !Q.u || !Q.v || !Q.radius || !Q.min_level || !Q.max_level || !Q.desc)) ||
+            (p->check_orientation && Q.n > 0 && !Q.angle) || (Q.u_right && !Q.right_gate) ||
+            (P.train.n > 0 && (!P.claimed || !P.claimed_obs || !P.train.kps || !P.train.desc))) {
+            orbx_set_error("job %d: invalid argument", i);
+            return ORBX_ERR_INVALID;
+        }
+        const size_t nq = (size_t)Q.n, nt = (size_t)P.train.n;
+        words += (GRID_CELLS + 1) + nt + nq + (nq + 1) + 2 * nq + 1 + 8;  // cellStart, cellItems, counts, offs, qBin, qBest, nmatches
+        bytes += 2 * nt + 16;                                             // cellOf
+        maxNq = std::max(maxNq, Q.n);
+    }
+    void *dJobs, *dWords, *dBytes, *dTot;
+    if ((rc = pool_get(m, SL_JB_JOBS, (size_t)njobs * sizeof(ProjJob), &dJobs)) ||
+        (rc = pool_get(m, SL_JB_I32, words * 4, &dWords)) || (rc = pool_get(m, SL_JB_U8, bytes, &dBytes)) ||
+        (rc = pool_get(m, SL_JB_TOT, ((size_t)njobs * 2 + 8) * sizeof(int), &dTot)))
+        return rc;
+    const int SLAB_CAP = 32;
+    size_t slabWords = 0;
+    for (int i = 0; i < njobs; i++) slabWords += (size_t)jobsIn[i].q.n * SLAB_CAP;
+    void* dSlab;
+    if ((rc = pool_get(m, SL_JB_SLAB, std::max(slabWords, (size_t)1) * 4, &dSlab))) return rc;
+    int* dOverflow = (int*)dTot + 2 * (size_t)njobs;
+    ORBX_HIP_CHECK(hipMemsetAsync(dOverflow, 0, sizeof(int), m->stream));
+    ProjJob* jobs = (ProjJob*)arena_alloc(m, (size_t)njobs * sizeof(ProjJob));
+    if (!jobs) return ORBX_ERR_HIP;
+    int* wp = (int*)dWords;
+    u8* bp = (u8*)dBytes;
+    int* nmArr = (int*)dTot + njobs;
+    size_t slabOff = 0;
+    for (int i = 0; i < njobs; i++) {
+        const orbm_projected_job& P = jobsIn[i];
+        ProjJob& J = jobs[i];
+        memset(&J, 0, sizeof(J));
+        if ((rc = make_frame(m, &P.train, 0, 0, ORBX_MEM_DEVICE, &J.train))) return rc;
+        const int nq = P.q.n, nt = P.train.n;
+        auto takeW = [&](size_t n) {
+            int* r = wp;
+            wp += n;
+            return r;
+        };
+        J.trainURight = P.train_u_right;
+        J.cellStart = takeW(GRID_CELLS + 1);
+        J.cellItems = takeW((size_t)nt);
+        J.counts = takeW((size_t)nq);
+        J.offs = takeW((size_t)nq + 1);
+        J.qBin = takeW((size_t)nq);
+        int* ownBest = takeW((size_t)nq);
+        wp += 8;
+        J.cellOf = (u16*)bp;
+        bp += 2 * (size_t)nt;
+        bp = (u8*)(((uintptr_t)bp + 15) & ~(uintptr_t)15);
+        J.claimed = (int*)P.claimed;
+        J.claimedObs = P.claimed_obs;
+        J.qBest = P.query_best ? (int*)P.query_best : ownBest;
+        J.nmatches = nmArr + i;
+        J.slab = (u32*)dSlab + slabOff;
+        J.slabCap = SLAB_CAP;
+        J.overflow = dOverflow;
+        slabOff += (size_t)nq * SLAB_CAP;
+        J.q.n = nq;
+        J.q.valid = P.q.valid;
+        J.q.u = P.q.u;
+        J.q.v = P.q.v;
+        J.q.radius = P.q.radius;
+        J.q.minLevel = P.q.min_level;
+        J.q.maxLevel = P.q.max_level;
+        J.q.desc = P.q.desc;
+        J.q.angle = P.q.angle;
+        J.q.hasObs = P.q.has_obs;  // NULL = every point has observations
+        J.q.uRight = P.q.u_right;
+        J.q.rightGate = P.q.right_gate;
+    }
+    ProjPolicy pol = {p->claim_rule, p->max_dist, p->ratio_test, p->nn_ratio, p->check_orientation};
+    if ((rc = run_projection_jobs(m, jobs, dJobs, njobs, maxNq, pol, false, nullptr, 0.f, window_hint > 0.f ? window_hint : 1e9f,
+                                  dTot, dOverflow, nmArr)))
+        return rc;
+    for (int i = 0; i < njobs; i++) jobsIn[i].nmatches = m->totalsHost[i];
     return ORBX_OK;
 }
 

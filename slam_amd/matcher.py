@@ -253,6 +253,29 @@ class ORBmatcher:
                                                         float(th), int(self.mbCheckOrientation)))
         return [arr[i].nmatches for i in range(len(arr))]
 
+    def SearchProjectedBatch(self, jobs, policy, window_hint=0.0):
+        """orbm_search_projected for many independent (frame, projected point set) jobs in one call: the batched
+        form of the SearchByProjection overloads that project map points (reference src/ORBmatcher.cc:62-164,
+        :370-485, :1694-1836).  `jobs`: list of dicts of torch DEVICE tensors: train_kps (n, 28) u8, train_desc
+        (n, 32) u8, bounds (4 floats), valid u8, u, v, radius f32, min_level, max_level i32, desc (nq, 32) u8,
+        claimed i32 and claimed_obs u8 (both in/out), optional train_u_right, angle, has_obs, u_right,
+        right_gate, query_best i32.  `policy` = (claim_rule, max_dist, ratio_test, nn_ratio, check_orientation).
+        Returns the list of match counts."""
+        arr = (_lib.ProjectedJob * len(jobs))()
+        ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        for i, p in enumerate(jobs):
+            arr[i].train = MFrame(p["train_kps"].data_ptr(), p["train_desc"].data_ptr(), p["train_kps"].shape[0], *p["bounds"])
+            arr[i].train_u_right = ptr(p.get("train_u_right"))
+            arr[i].q = _lib.ProjQueries(p["valid"].shape[0], ptr(p["valid"]), ptr(p["u"]), ptr(p["v"]), ptr(p["radius"]),
+                                        ptr(p["min_level"]), ptr(p["max_level"]), ptr(p["desc"]), ptr(p.get("angle")),
+                                        ptr(p.get("has_obs")), ptr(p.get("u_right")), ptr(p.get("right_gate")))
+            arr[i].claimed = p["claimed"].data_ptr()
+            arr[i].claimed_obs = p["claimed_obs"].data_ptr()
+            arr[i].query_best = ptr(p.get("query_best"))
+        pol = _lib.ProjPolicy(int(policy[0]), int(policy[1]), int(policy[2]), float(policy[3]), int(policy[4]))
+        check(self._lib.orbm_search_projected_batch(self._m, arr, len(arr), C.byref(pol), float(window_hint)))
+        return [arr[i].nmatches for i in range(len(arr))]
+
     # ---- vocabulary-guided searches
     @staticmethod
     def feature_vector(fv):

@@ -413,6 +413,100 @@ def test_search_by_projection_batch_equals_oracle_per_pair(oracle, frames, th):
     assert sum(counts) > 500
 
 
+@pytest.mark.parametrize("variant", ["map_points", "keyframe", "sim3"])
+def test_search_projected_batch_equals_oracle_per_job(oracle, frames, variant):
+    """The map-point overloads of SearchByProjection for many independent jobs in one call
+    (device-resident): every job must equal the oracle's result for that job, including jobs with
+    prior claims, no queries, and window hints of every walk form."""
+    import torch
+    from slam_amd.matcher import ORBmatcher
+    kb, db = frames["b"]
+    sf = frames["sf"]
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    ratio, th, orbdist = 0.8, 3.0, 100
+    jobs, cases = [], []
+    for i in range(7):
+        q = map_point_inputs(frames, 20 + i)
+        rng = np.random.RandomState(40 + i)
+        n = len(q["px"]) if i != 5 else 0            # job 5: no queries
+        if i == 6:
+            n = 257
+        for k in ("valid", "px", "py", "pxr", "level", "view_cos", "desc", "has_obs", "angle"):
+            q[k] = q[k][:n]
+        claimed = np.full(len(kb), -1, np.int32)
+        cobs = np.zeros(len(kb), np.uint8)
+        if i % 2:                                     # prior claims
+            pick = rng.uniform(size=len(kb)) < 0.2
+            claimed[pick] = 3
+            cobs[pick] = (rng.uniform(size=pick.sum()) < 0.7).astype(np.uint8)
+        level = q["level"].astype(np.int32)
+        if variant == "map_points":
+            r = np.where(q["view_cos"].astype(np.float64) > 0.998, np.float32(2.5), np.float32(4.0)).astype(np.float32)
+            r = (r * np.float32(th)).astype(np.float32)
+            radius = (r * sf[level]).astype(np.float32)
+            lo, hi, valid = level - 1, level, q["valid"]
+            pol = (0, 100, 1, ratio, 0)
+            extra = dict(has_obs=t(q["has_obs"]), u_right=t(q["pxr"]), right_gate=t(radius), train_u_right=t(q["ur"]))
+        elif variant == "keyframe":
+            radius = (np.float32(10.0) * sf[level]).astype(np.float32)
+            lo, hi = level - 1, level + 1
+            ok = q["valid"].astype(bool) & ~((q["px"] < np.float32(BOUNDS[0])) | (q["px"] > np.float32(BOUNDS[2]))) & \
+                ~((q["py"] < np.float32(BOUNDS[1])) | (q["py"] > np.float32(BOUNDS[3])))
+            valid = ok.astype(np.uint8)
+            pol = (1, orbdist, 0, 0.0, 1)
+            extra = dict(angle=t(q["angle"]))
+        else:
+            radius = (np.float32(10) * sf[level]).astype(np.float32)
+            lo, hi = level - 1, level
+            inimg = (q["px"] >= np.float32(BOUNDS[0])) & (q["px"] < np.float32(BOUNDS[2])) & \
+                (q["py"] >= np.float32(BOUNDS[1])) & (q["py"] < np.float32(BOUNDS[3]))
+            valid = (q["valid"].astype(bool) & inimg).astype(np.uint8)
+            pol = (1, 50, 0, 0.0, 0)
+            extra = {}
+        job = dict(train_kps=t(kb.view(np.uint8).reshape(-1, 28)), train_desc=t(db), bounds=BOUNDS, valid=t(valid),
+                   u=t(q["px"]), v=t(q["py"]), radius=t(radius), min_level=t(lo.astype(np.int32)),
+                   max_level=t(hi.astype(np.int32)), desc=t(q["desc"].reshape(-1, 32)), claimed=t(claimed), claimed_obs=t(cobs),
+                   query_best=torch.full((max(n, 1),), -5, dtype=torch.int32, device=dev), **extra)
+        jobs.append(job)
+        cases.append((q, claimed, cobs))
+    m = ORBmatcher(ratio, True)
+    try:
+        counts = None
+        for hint in (0.0, 8.0, 15.0):
+            for job, (q, claimed, cobs) in zip(jobs, cases):   # restore the in/out state
+                job["claimed"].copy_(t(claimed))
+                job["claimed_obs"].copy_(t(cobs))
+            torch.cuda.synchronize()
+            c = m.SearchProjectedBatch(jobs, pol, hint)
+            torch.cuda.synchronize()
+            res = [(j["claimed"].cpu().numpy().copy(), j["claimed_obs"].cpu().numpy().copy()) for j in jobs]
+            if counts is not None:
+                assert c == counts
+                for (a, b), (a2, b2) in zip(res, first):
+                    assert np.array_equal(a, a2) and np.array_equal(b, b2)
+            else:
+                counts, first = c, res
+    finally:
+        m.close()
+    oF = oracle.FrameData(kb, db, BOUNDS, sf)
+    for (q, claimed, cobs), (cl, co), n in zip(cases, first, counts):
+        if variant == "map_points":
+            rn, rcl, rco = oracle.search_by_projection_mappoints(oF, q["ur"], q["valid"], q["px"], q["py"], q["pxr"],
+                                                                 q["level"], q["view_cos"], q["desc"], q["has_obs"], th,
+                                                                 ratio, claimed.copy(), cobs.copy())
+            assert np.array_equal(co, rco)
+        elif variant == "keyframe":
+            rn, rcl = oracle.search_by_projection_keyframe(oF, q["valid"], q["px"], q["py"], q["level"], q["desc"],
+                                                           q["angle"], 10.0, orbdist, True, claimed.copy())
+        else:
+            rn, rcl = oracle.search_by_projection_sim3(oF, q["valid"], q["px"], q["py"], q["level"], q["desc"], 10,
+                                                       claimed.copy())
+        assert n == rn
+        assert np.array_equal(cl, rcl)
+    assert sum(counts) > 300
+
+
 def test_random_frames_and_parameters_equal_oracle():
     """A seeded sweep over synthetic frame pairs (empty and tiny frames, clustered keypoints,
     non-zero image bounds, descriptors with many equal distances) and over the parameters of
