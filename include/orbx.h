@@ -435,6 +435,25 @@ int orbm_search_by_projection_batch(orbm_context* m, orbm_projection_pair* pairs
                                     const float* scale_factors, int nlevels, float bf, float th,
                                     int check_orientation);
 
+/* Many independent SearchByBoW calls in one set of launches (relocalisation and loop detection match
+ * one frame or keyframe against many candidate keyframes, reference src/Tracking.cc:1609-1625,
+ * src/LoopClosing.cc:239-258): orbm_search_by_bow for every entry of `jobs` with shared max_dist,
+ * nn_ratio and check_orientation.  Every array a job points to is DEVICE memory (the job table itself is
+ * host memory) and meets the preconditions stated for device feature vectors above; valid2 may be
+ * NULL (the (KeyFrame*, Frame&) overload); match12 (f1.n) and match21 (f2.n) are outputs, nmatches is
+ * written on return. */
+typedef struct orbm_bow_job {
+    orbm_frame f1, f2;
+    orbm_feature_vector fv1, fv2;
+    const uint8_t* valid1; /* f1.n */
+    const uint8_t* valid2; /* f2.n or NULL */
+    int32_t* match12;      /* f1.n, out */
+    int32_t* match21;      /* f2.n, out */
+    int32_t nmatches;      /* out */
+} orbm_bow_job;
+int orbm_search_by_bow_batch(orbm_context* m, orbm_bow_job* jobs, int njobs, int max_dist, float nn_ratio,
+                             int check_orientation);
+
 /* Many independent projected searches in one call: orbm_search_projected for every entry of `jobs`
  * under one policy, i.e. the batched form of the three SearchByProjection overloads that project map
  * points into a frame or keyframe (reference src/ORBmatcher.cc:62-164, :370-485, :1694-1836; the

@@ -76,6 +76,11 @@ class FeatureVector(C.Structure):
                 ("items", C.c_void_p)]
 
 
+class BowJob(C.Structure):
+    _fields_ = [("f1", MFrame), ("f2", MFrame), ("fv1", FeatureVector), ("fv2", FeatureVector), ("valid1", C.c_void_p),
+                ("valid2", C.c_void_p), ("match12", C.c_void_p), ("match21", C.c_void_p), ("nmatches", C.c_int32)]
+
+
 # Every exported symbol of include/orbx.h: (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -141,6 +146,7 @@ SIGNATURES = {
     "orbm_compute_stereo_matches": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), C.POINTER(Pyramid),
                                          C.POINTER(Pyramid), _vp, _vp, _f, _f, _vp, _vp, _vp, _i]),
     "orbm_search_by_projection_batch": (_i, [_vp, C.POINTER(ProjectionPair), _i, _vp, _i, _f, _f, _i]),
+    "orbm_search_by_bow_batch": (_i, [_vp, C.POINTER(BowJob), _i, _i, _f, _i]),
     "orbm_search_projected_batch": (_i, [_vp, C.POINTER(ProjectedJob), _i, C.POINTER(ProjPolicy), _f]),
     "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
     "orbm_bow_transform": (_i, [_vp, C.POINTER(Vocabulary), _vp, _i, _i, _vp, _vp, _vp, _i]),

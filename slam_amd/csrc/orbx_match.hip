@@ -1304,10 +1304,10 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
 // belong to one node only, so the claims of different nodes never meet; inside a node the
 // first-side keypoints are taken in list order and the second-side list is scanned by the
 // 64 lanes (best = smallest distance, first in list order; second best counts duplicates).
-__global__ __launch_bounds__(64) void k_bow_match(DevFrame f1, DevFeatVec v1, const u8* __restrict__ valid1, DevFrame f2,
-                                                   DevFeatVec v2, const u8* __restrict__ valid2, int maxDist, float nnRatio,
-                                                   int checkOri, int* match12, int* match21, int* bin12, int* hist) {
-    const int n1 = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void bow_match_body(const int n1, DevFrame f1, DevFeatVec v1, const u8* __restrict__ valid1,
+                                               DevFrame f2, DevFeatVec v2, const u8* __restrict__ valid2, int maxDist,
+                                               float nnRatio, int checkOri, int* match12, int* match21, int* bin12, int* hist) {
+    const int lane = threadIdx.x;
     const int n2 = find_node(v2, v1.nodeIds[n1]);
     if (n2 < 0) return;
     const int b2 = v2.start[n2], e2 = v2.start[n2 + 1];
@@ -1497,10 +1497,39 @@ __global__ __launch_bounds__(64) void k_tri_match(DevFrame f1, DevFeatVec v1, co
     }
 }
 
+// One vocabulary node of the first side per workgroup; a single pair, or one pair ("job") per blockIdx.y.
+struct BowJob {
+    DevFrame f1, f2;
+    DevFeatVec v1, v2;
+    const u8 *valid1, *valid2;
+    int *match12, *match21, *bin12, *hist;  // hist: HISTO_LENGTH bins + the match count + one spare
+};
+__global__ __launch_bounds__(64) void k_bow_match(DevFrame f1, DevFeatVec v1, const u8* __restrict__ valid1, DevFrame f2,
+                                                   DevFeatVec v2, const u8* __restrict__ valid2, int maxDist, float nnRatio,
+                                                   int checkOri, int* match12, int* match21, int* bin12, int* hist) {
+    bow_match_body((int)blockIdx.x, f1, v1, valid1, f2, v2, valid2, maxDist, nnRatio, checkOri, match12, match21, bin12, hist);
+}
+__global__ __launch_bounds__(64) void k_bow_match_jobs(const BowJob* __restrict__ jobs, int maxDist, float nnRatio, int checkOri) {
+    const BowJob& J = jobs[blockIdx.y];
+    if ((int)blockIdx.x >= J.v1.nNodes || J.v2.nNodes == 0 || J.f1.n == 0 || J.f2.n == 0) return;
+    bow_match_body((int)blockIdx.x, J.f1, J.v1, J.valid1, J.f2, J.v2, J.valid2, maxDist, nnRatio, checkOri, J.match12, J.match21,
+                   J.bin12, J.hist);
+}
+__global__ void k_bow_init_jobs(const BowJob* __restrict__ jobs) {
+    const BowJob& J = jobs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < J.f1.n) {
+        J.match12[i] = -1;
+        J.bin12[i] = -1;
+    }
+    if (i < J.f2.n) J.match21[i] = -1;
+    if (i < HISTO_LENGTH + 2) J.hist[i] = 0;
+}
+
 // Rotation-consistency cull shared by the two kernels above (reference
 // src/ORBmatcher.cc:330-352): keep the three fullest bins, count what is left.
-__global__ __launch_bounds__(256) void k_bow_finish(int n1, int checkOri, int* match12, int* match21, const int* bin12,
-                                                     const int* hist, int* nmatchesOut) {
+__device__ __forceinline__ void bow_finish_body(int n1, int checkOri, int* match12, int* match21, const int* bin12,
+                                                const int* hist, int* nmatchesOut) {
     __shared__ int keep[3];
     __shared__ int total;
     const int tid = threadIdx.x;
@@ -1530,6 +1559,14 @@ __global__ __launch_bounds__(256) void k_bow_finish(int n1, int checkOri, int* m
     atomicAdd(&total, mine);
     __syncthreads();
     if (tid == 0) *nmatchesOut = total;
+}
+__global__ __launch_bounds__(256) void k_bow_finish(int n1, int checkOri, int* match12, int* match21, const int* bin12,
+                                                     const int* hist, int* nmatchesOut) {
+    bow_finish_body(n1, checkOri, match12, match21, bin12, hist, nmatchesOut);
+}
+__global__ __launch_bounds__(256) void k_bow_finish_jobs(const BowJob* __restrict__ jobs, int checkOri, int* counts) {
+    const BowJob& J = jobs[blockIdx.x];
+    bow_finish_body(J.f1.n, checkOri, J.match12, J.match21, J.bin12, J.hist, counts + blockIdx.x);
 }
 
 struct WindowBestParams {
@@ -3609,6 +3646,76 @@ int orbm_search_by_bow(orbm_context* m, const orbm_frame* f1, const orbm_feature
     if ((rc = copy_back(m, (int*)match21, (const int*)dM21, (size_t)d2.n, mem_space))) return rc;
     if ((rc = d2h(m, nmatches, dCount, sizeof(int)))) return rc;
     ORBX_HIP_CHECK(sync_deliver(m));
+    return ORBX_OK;
+}
+
+int orbm_search_by_bow_batch(orbm_context* m, orbm_bow_job* jobsIn, int njobs, int max_dist, float nn_ratio,
+                             int check_orientation) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (njobs < 0 || (njobs > 0 && !jobsIn)) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (njobs == 0) return ORBX_OK;
+    size_t words = 0;
+    int maxNodes = 0, maxN = HISTO_LENGTH + 2;
+    for (int i = 0; i < njobs; i++) {
+        const orbm_bow_job& P = jobsIn[i];
+        const bool fvBad = P.fv1.n_nodes < 0 || P.fv2.n_nodes < 0 || P.fv1.n_items < 0 || P.fv2.n_items < 0 ||
+                           (P.fv1.n_nodes > 0 && (!P.fv1.node_ids || !P.fv1.start)) ||
+                           (P.fv2.n_nodes > 0 && (!P.fv2.node_ids || !P.fv2.start)) || (P.fv1.n_items > 0 && !P.fv1.items) ||
+                           (P.fv2.n_items > 0 && !P.fv2.items);
+        if (P.f1.n < 0 || P.f2.n < 0 || fvBad || (P.f1.n > 0 && (!P.valid1 || !P.match12 || !P.f1.kps || !P.f1.desc)) ||
+            (P.f2.n > 0 && (!P.match21 || !P.f2.kps || !P.f2.desc))) {
+            orbx_set_error("job %d: invalid argument", i);
+            return ORBX_ERR_INVALID;
+        }
+        words += (size_t)std::max(P.f1.n, 1) + HISTO_LENGTH + 2;
+        maxNodes = std::max(maxNodes, P.fv1.n_nodes);
+        maxN = std::max(maxN, std::max(P.f1.n, P.f2.n));
+    }
+    void *dJobs, *dWords, *dCounts;
+    if ((rc = pool_get(m, SL_JB_JOBS, (size_t)njobs * sizeof(BowJob), &dJobs)) || (rc = pool_get(m, SL_JB_I32, words * 4, &dWords)) ||
+        (rc = pool_get(m, SL_JB_TOT, (size_t)njobs * sizeof(int), &dCounts)))
+        return rc;
+    BowJob* jobs = (BowJob*)arena_alloc(m, (size_t)njobs * sizeof(BowJob));
+    if (!jobs) return ORBX_ERR_HIP;
+    int* wp = (int*)dWords;
+    for (int i = 0; i < njobs; i++) {
+        const orbm_bow_job& P = jobsIn[i];
+        BowJob& J = jobs[i];
+        memset(&J, 0, sizeof(J));
+        if ((rc = make_frame(m, &P.f1, 0, 0, ORBX_MEM_DEVICE, &J.f1)) || (rc = make_frame(m, &P.f2, 0, 0, ORBX_MEM_DEVICE, &J.f2)))
+            return rc;
+        J.v1.nNodes = P.fv1.n_nodes;
+        J.v1.nodeIds = P.fv1.node_ids;
+        J.v1.start = P.fv1.start;
+        J.v1.items = P.fv1.items;
+        J.v2.nNodes = P.fv2.n_nodes;
+        J.v2.nodeIds = P.fv2.node_ids;
+        J.v2.start = P.fv2.start;
+        J.v2.items = P.fv2.items;
+        J.valid1 = P.valid1;
+        J.valid2 = P.valid2;
+        J.match12 = P.match12;
+        J.match21 = P.match21;
+        J.bin12 = wp;
+        wp += std::max(P.f1.n, 1);
+        J.hist = wp;
+        wp += HISTO_LENGTH + 2;
+    }
+    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, (size_t)njobs * sizeof(BowJob), hipMemcpyHostToDevice, m->stream));
+    const BowJob* dJ = (const BowJob*)dJobs;
+    ORBM_LAUNCH(k_bow_init_jobs, dim3((maxN + 255) / 256, njobs), dim3(256), 0, m->stream, dJ);
+    if (maxNodes > 0)
+        ORBM_LAUNCH(k_bow_match_jobs, dim3(maxNodes, njobs), dim3(64), 0, m->stream, dJ, max_dist, nn_ratio, check_orientation);
+    ORBM_LAUNCH(k_bow_finish_jobs, dim3(njobs), dim3(256), 0, m->stream, dJ, check_orientation, (int*)dCounts);
+    ORBX_HIP_CHECK(hipGetLastError());
+    m->totalsHost.resize((size_t)njobs);
+    if ((rc = d2h(m, m->totalsHost.data(), dCounts, (size_t)njobs * sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
+    for (int i = 0; i < njobs; i++) jobsIn[i].nmatches = m->totalsHost[i];
     return ORBX_OK;
 }
 

@@ -292,6 +292,29 @@ class ORBmatcher:
         s = _lib.FeatureVector(len(pairs), int(start[-1]), ids.ctypes.data, start.ctypes.data, items.ctypes.data)
         return s, (ids, start, items)
 
+    def SearchByBoWBatch(self, jobs, keyframe_pair=False):
+        """SearchByBoW for many independent pairs in one set of launches (device-resident).  `jobs`: list of dicts
+        of torch DEVICE tensors: kps1 (n1, 28) u8, desc1 (n1, 32) u8, kps2, desc2, bounds (4 floats), valid1 u8,
+        optional valid2 u8, match12 i32 (n1) and match21 i32 (n2) outputs, and the two feature vectors as
+        fv1_ids / fv1_start / fv1_items, fv2_ids / fv2_start / fv2_items (u32 / i32 / u32, CSR, ids ascending).
+        Returns the list of match counts."""
+        arr = (_lib.BowJob * len(jobs))()
+        for i, p in enumerate(jobs):
+            arr[i].f1 = MFrame(p["kps1"].data_ptr(), p["desc1"].data_ptr(), p["kps1"].shape[0], *p["bounds"])
+            arr[i].f2 = MFrame(p["kps2"].data_ptr(), p["desc2"].data_ptr(), p["kps2"].shape[0], *p["bounds"])
+            for side in ("1", "2"):
+                ids, st, it = p["fv%s_ids" % side], p["fv%s_start" % side], p["fv%s_items" % side]
+                fv = _lib.FeatureVector(ids.shape[0], it.shape[0], ids.data_ptr() if ids.shape[0] else None, st.data_ptr(),
+                                        it.data_ptr() if it.shape[0] else None)
+                setattr(arr[i], "fv" + side, fv)
+            arr[i].valid1 = p["valid1"].data_ptr()
+            arr[i].valid2 = p["valid2"].data_ptr() if p.get("valid2") is not None else None
+            arr[i].match12 = p["match12"].data_ptr()
+            arr[i].match21 = p["match21"].data_ptr()
+        check(self._lib.orbm_search_by_bow_batch(self._m, arr, len(arr), self.TH_LOW - 1 if keyframe_pair else self.TH_LOW,
+                                                 float(self.mfNNratio), int(self.mbCheckOrientation)))
+        return [arr[i].nmatches for i in range(len(arr))]
+
     def SearchByBoW(self, F1, fv1, valid1, F2, fv2, valid2=None, keyframe_pair=False):
         """ORBmatcher::SearchByBoW.  keyframe_pair=False: (KeyFrame*, Frame&) overload (reference
         src/ORBmatcher.cc:209-355), accepts distances <= TH_LOW; True: (KeyFrame*, KeyFrame*)

@@ -96,6 +96,67 @@ def test_search_by_bow(oracle, pair, nodes, kfpair, ori, ratio):
     assert np.array_equal(m21[m12[idx]], idx)
 
 
+@pytest.mark.parametrize("kfpair,ori", [(False, True), (True, True), (False, False)])
+def test_search_by_bow_batch_equals_oracle_per_job(oracle, pair, kfpair, ori):
+    """One frame against many candidate keyframes in one set of launches (relocalisation / loop
+    detection): every job must equal the oracle's result for that job, including jobs with a
+    single node, no shared node, an empty feature vector and an empty second frame."""
+    import torch
+    from slam_amd.matcher import ORBmatcher
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    sx, sy = pair["shift"]
+    ka, da, kb, db = pair["ka"], pair["da"], pair["kb"], pair["db"]
+    ratio = 0.75
+
+    def csr(fv):
+        ids = np.array(sorted(fv), np.uint32)
+        start = np.zeros(len(ids) + 1, np.int32)
+        for i, k in enumerate(ids):
+            start[i + 1] = start[i] + len(fv[int(k)])
+        items = np.array([x for k in ids for x in fv[int(k)]], np.uint32)
+        return t(ids), t(start), t(items)
+
+    jobs, cases = [], []
+    for i, nodes in enumerate((97, 13, 1, 400, 97, 97, 97)):
+        r = np.random.default_rng(100 + i)
+        k2, d2 = kb, db
+        fva = feature_vector(node_of(ka, 0, 0, nodes, 10 + i), 30 + i)
+        fvb = feature_vector(node_of(kb, -sx, -sy, nodes, 20 + i), 40 + i)
+        if i == 4:      # no shared node
+            fvb = {k + 1: v for k, v in fvb.items()}
+        if i == 5:      # empty first feature vector
+            fva = {}
+        if i == 6:      # empty second frame
+            k2, d2, fvb = kb[:0], db[:0], {}
+        valid1 = (r.uniform(size=len(ka)) < 0.8).astype(np.uint8)
+        valid2 = (r.uniform(size=len(k2)) < 0.7).astype(np.uint8) if kfpair else None
+        a_ids, a_st, a_it = csr(fva)
+        b_ids, b_st, b_it = csr(fvb)
+        jobs.append(dict(kps1=t(ka.view(np.uint8).reshape(-1, 28)), desc1=t(da), kps2=t(k2.view(np.uint8).reshape(-1, 28)),
+                         desc2=t(d2.reshape(-1, 32)), bounds=BOUNDS, valid1=t(valid1),
+                         valid2=t(valid2) if valid2 is not None else None,
+                         match12=torch.full((len(ka),), -7, dtype=torch.int32, device=dev),
+                         match21=torch.full((max(len(k2), 1),), -7, dtype=torch.int32, device=dev),
+                         fv1_ids=a_ids, fv1_start=a_st, fv1_items=a_it, fv2_ids=b_ids, fv2_start=b_st, fv2_items=b_it))
+        cases.append((fva, fvb, valid1, valid2, k2, d2))
+    m = ORBmatcher(ratio, ori)
+    try:
+        torch.cuda.synchronize()
+        counts = m.SearchByBoWBatch(jobs, keyframe_pair=kfpair)
+        torch.cuda.synchronize()
+    finally:
+        m.close()
+    oa = oracle.FrameData(ka, da, BOUNDS, pair["sf"])
+    for (fva, fvb, valid1, valid2, k2, d2), job, n in zip(cases, jobs, counts):
+        ob = oracle.FrameData(k2, d2, BOUNDS, pair["sf"])
+        on, o12, o21 = oracle.search_by_bow(oa, fva, valid1, ob, fvb, valid2, 49 if kfpair else 50, ratio, ori)
+        assert n == on
+        assert np.array_equal(job["match12"].cpu().numpy(), o12)
+        assert np.array_equal(job["match21"].cpu().numpy()[:len(k2)], o21)
+    assert sum(counts) > 150
+
+
 def test_search_by_bow_disjoint_and_empty(oracle, pair, matcher):
     ga, gb, oa, ob = frames(pair, oracle)
     fva = {2: [0, 1, 2], 8: [3, 4]}
