@@ -517,7 +517,9 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, ImgRef img0, const u8* __r
     }
 }
 
+#ifndef BLUR_BH
 #define BLUR_BH 84  // output rows per band (a multiple of the 7-row window; 28..168 measured, 84 fastest)
+#endif
 
 // Streaming form of the same filter: no LDS, no barriers.  A lane owns a column
 // of 4 pixels and walks down a band of rows keeping the last 7 horizontal sums
@@ -666,6 +668,175 @@ __global__ __launch_bounds__(256) void k_blur_stream(Geom g, ImgRef img0, const 
     // Two register sets used alternately (no copy from "next" to "current", which would wait for the
     // loads at the end of every group): a set is refilled right after its rows have been filtered.
     Raw other[7];
+    int yb = y0;
+    while (true) {
+        if (yb + 7 < yEnd) load_group(other, yb + 10);
+        run_group(cur, yb);
+        yb += 7;
+        if (yb >= yEnd) break;
+        if (yb + 7 < yEnd) load_group(cur, yb + 10);
+        run_group(other, yb);
+        yb += 7;
+        if (yb >= yEnd) break;
+    }
+}
+
+// The same filter with wave-uniform control, as in the resize: a wave owns one band of one level for
+// W column groups x K = 64 / W frames (lane = frame slot * W + group), so the row walk, the reflected
+// row indices, the phase of the 7-row ring and every branch are scalar, and a row of a lane's window
+// is ONE 12-byte buffer load (descriptor of the wave's first frame + scalar row offset + a per-lane
+// offset fixed at start-up) instead of three word loads with per-lane addresses.  The word before
+// the first group's window starts at its own word (the selectors of that lane account for it), and the
+// word after the last group is loaded but never selected.  Arithmetic and selectors are those of
+// k_blur_stream.  task = (level, band, chunk of W groups); tasks of a level are contiguous from its
+// blurTaskBase.
+struct BlurRowsArgs {
+    int taskBase[ORBX_MAX_LEVELS + 1];  // first task of each level; [nlevels] = total
+    int chunks[ORBX_MAX_LEVELS];        // chunks of W groups per row of the level
+    int logW;
+    int firstLevel;
+};
+template <bool HALF_EVEN>
+__global__ __launch_bounds__(256) void k_blur_rows(Geom g, ImgRef img0, const u8* __restrict__ pyr, u8* __restrict__ blur,
+                                                    int k0, int k1, int k2, int k3, BlurRowsArgs A, int nFrames) {
+    const int lane = threadIdx.x & 63;
+    const int task = (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (task >= A.taskBase[g.nlevels]) return;
+    int l = A.firstLevel;
+    while (l + 1 < g.nlevels && task >= A.taskBase[l + 1]) l++;
+    const LevelGeom& L = g.lv[l];
+    const int t = task - A.taskBase[l];
+    const int chunks = A.chunks[l];
+    const int band = t / chunks, chunk = t - band * chunks;
+    const int logW = A.logW, K = 64 >> logW;
+    const int gx = (chunk << logW) + (lane & ((1 << logW) - 1));
+    const int fk = lane >> logW;
+    const int f0 = (int)blockIdx.x * K;
+    const int G = L.blurGroups;
+    if (gx >= G || f0 + fk >= nFrames) return;
+    const int w = L.w, h = L.h;
+    const ImgRef im = level_image(g, l, img0, pyr);
+    const int srcPitch = im.pitch, dstPitch = L.blurPitch;
+    const __amdgpu_buffer_rsrc_t srcRs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(im.base + (i64)f0 * im.frameStride), 0, (int)((u32)K * (u32)im.frameStride), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dstRs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(blur + (i64)f0 * g.blurFrameBytes + L.blurOff), 0, (int)((u32)K * (u32)g.blurFrameBytes), 0x00020000);
+    // the lane's 12-byte window holds words wa, wa + 1, wa + 2 of a row (registers A, C, B): wa = gx - 1,
+    // except for the first group, whose window starts at its own word
+    const int wa = max(gx - 1, 0);
+    const int offS = (int)((u32)fk * (u32)im.frameStride) + 4 * wa;
+    const int offD = (int)((u32)fk * (u32)g.blurFrameBytes) + 4 * gx;
+    const bool lastGroup = gx == G - 1 && gx > 0;
+    const u32 tailUp = (gx == G - 1 && (w & 3)) ? 1u : 0u;
+
+    // byte selectors for the 12 positions x = 4*gx-4 .. 4*gx+7
+    u32 selL = 0, selC = 0, selR = 0;
+#pragma unroll
+    for (int p = 0; p < 12; p++) {
+        const int x = min(max(4 * gx - 4 + p, -3), w + 2);
+        int xr = x < 0 ? -x : x;  // single-step reflect-101 (w >= 4 here)
+        xr = xr >= w ? 2 * (w - 1) - xr : xr;
+        const int gs = xr >> 2, bs = xr & 3;
+        u32 code;
+        if (p < 8) {
+            // sources: S1 = register A (0..3), S0 = register C (4..7)
+            code = gs == wa + 1 ? 4 + bs : gs == wa ? bs : 4;
+        } else {
+            // sources: S1 = register B (register A for the last group), S0 = register C
+            const int ga = lastGroup ? wa : wa + 2;
+            code = gs == wa + 1 ? 4 + bs : gs == ga ? bs : 4;
+        }
+        if (p < 4) selL |= code << (8 * p);
+        else if (p < 8) selC |= code << (8 * (p - 4));
+        else selR |= code << (8 * (p - 8));
+    }
+    const u32 W1 = (u32)k0 | ((u32)k1 << 8) | ((u32)k2 << 16) | ((u32)k3 << 24);
+    const u32 W2 = (u32)k2 | ((u32)k1 << 8) | ((u32)k0 << 16);
+    const int y0 = band * BLUR_BH;
+    const int yEnd = min(y0 + BLUR_BH, h);
+
+    typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+    auto fetch = [&](int y) {
+        // one reflection covers y in [-3, h+2] (h >= 4 here); all of it scalar
+        y = min(y, h + 2);
+        int r = y < 0 ? -y : y;
+        r = r >= h ? 2 * (h - 1) - r : r;
+        return __builtin_amdgcn_raw_buffer_load_b96(srcRs, offS, r * srcPitch, 0);
+    };
+    auto hrow = [&](const u32x3& rw, u32* hs) {
+        const u32 a = rw[0], c = rw[1], b = rw[2];
+        const u32 Lw = __builtin_amdgcn_perm(c, a, selL);
+        const u32 Cw = __builtin_amdgcn_perm(c, a, selC);
+        const u32 Rw = __builtin_amdgcn_perm(c, lastGroup ? a : b, selR);
+        // output j uses bytes j+1..j+4 (taps k0..k3) and j+5..j+7 (taps k2,k1,k0)
+        hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), W2,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), W1, 0u, false), false);
+        hs[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), W2,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), W1, 0u, false), false);
+        hs[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), W2,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), W1, 0u, false), false);
+        hs[3] = __builtin_amdgcn_udot4(Rw, W2, __builtin_amdgcn_udot4(Cw, W1, 0u, false), false);
+    };
+    // Vertical pass on pairs of consecutive rows: P_r = (hs[r-1], hs[r]) as two 16-bit halves
+    // (row sums are < 2^16), so that output row y is four v_dot2_u32_u16:
+    //   P[y-2].(k0,k1) + P[y].(k2,k3) + P[y+2].(k2,k1) + P[y+3].(0,k0) + 32768.
+    // win[] is a ring of the last seven P (slot (ph + 6) % 7 receives P[y+3] at phase ph).
+    const u32 W01 = (u32)k0 | ((u32)k1 << 16), W23 = (u32)k2 | ((u32)k3 << 16), W21 = (u32)k2 | ((u32)k1 << 16),
+              W0h = (u32)k0 << 16;
+    u32 win[7][4], lastHs[4];
+    u32x3 cur[7];
+    {
+        u32x3 ini[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) ini[i] = fetch(y0 - 3 + i);
+#pragma unroll
+        for (int i = 0; i < 7; i++) cur[i] = fetch(y0 + 3 + i);
+        u32 h0[4], h1[4];
+        hrow(ini[0], h0);
+#pragma unroll
+        for (int i = 1; i < 6; i++) {
+            hrow(ini[i], h1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                win[i][k] = h0[k] | (h1[k] << 16);
+                h0[k] = h1[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) lastHs[k] = h0[k];
+    }
+    auto load_group = [&](u32x3* grp, int yFirst) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) grp[i] = fetch(yFirst + i);
+    };
+    auto run_group = [&](const u32x3* grp, int yb) {
+#pragma unroll
+        for (int ph = 0; ph < 7; ph++) {
+            const int y = yb + ph;
+            u32 hs[4];
+            hrow(grp[ph], hs);
+            // The rounded sum is < 2^25; clamped to 0xFFFFFF its byte 2 is the saturated output pixel.
+            u32 sv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 P3 = lastHs[k] | (hs[k] << 16);
+                win[(ph + 6) % 7][k] = P3;
+                lastHs[k] = hs[k];
+                u32 s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 1) % 7][k]), as_u16x2(W01), HALF_EVEN ? 0u : 32768u, false);
+                s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 3) % 7][k]), as_u16x2(W23), s, false);
+                s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 5) % 7][k]), as_u16x2(W21), s, false);
+                s = __builtin_amdgcn_udot2(as_u16x2(P3), as_u16x2(W0h), s, false);
+                if (HALF_EVEN) s += 0x7FFFu + (((s >> 16) & 1u) | tailUp);  // ties to even; the image's last w % 4 columns half up
+                sv[k] = min(s, 0xFFFFFFu);
+            }
+            const u32 lo = __builtin_amdgcn_perm(sv[1], sv[0], 0x0c0c0602u);  // bytes: sv0[2], sv1[2], 0, 0
+            const u32 hi = __builtin_amdgcn_perm(sv[3], sv[2], 0x06020c0cu);  // bytes: 0, 0, sv2[2], sv3[2]
+            const u32 out = lo | hi;
+            if (y < yEnd) __builtin_amdgcn_raw_buffer_store_b32(out, dstRs, offD, y * dstPitch, 0);  // scalar branch
+        }
+    };
+    // Two register sets used alternately: a set is refilled right after its rows have been filtered.
+    u32x3 other[7];
     int yb = y0;
     while (true) {
         if (yb + 7 < yEnd) load_group(other, yb + 10);
@@ -1902,6 +2073,8 @@ struct orbx_handle {
     PyramidArgs pyrArgs;                   // per-level arguments of the one-launch pyramid
     bool pyrFrameOk = false;               // every level fits the one-launch pyramid's assumptions
     int pyrFused = -1;                     // ORBX_PYR_FUSED: 1 / 0 forces the one-launch pyramid on / off (-1: by batch size)
+    int blurLogW = 0;                      // ORBX_BLUR_LOGW: forces the lane split of the wave-uniform blur (measurement knob)
+    bool blurRows = true;                  // ORBX_BLUR_ROWS=0: per-lane form of the streaming blur (measurement knob)
     int maxPipes = 3;                      // ORBX_NPIPES: passes in flight (measurement knob)
     bool forkBlur = true;                  // ORBX_FORK_BLUR=0: the blur stays on the pass's own stream
     int blurLds = 0;                       // ORBX_BLUR_LDS: unused LDS bytes per blur workgroup, caps its share of a compute unit (measurement knob)
@@ -2170,6 +2343,8 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     if (const char* e = getenv("ORBX_RESIZE_ROWS")) h->resizeRows = atoi(e) != 0;  // measurement knob
     if (const char* e = getenv("ORBX_RESIZE_LOGW")) h->resizeLogW = atoi(e);
     if (const char* e = getenv("ORBX_PYR_FUSED")) h->pyrFused = atoi(e);
+    if (const char* e = getenv("ORBX_BLUR_ROWS")) h->blurRows = atoi(e) != 0;
+    if (const char* e = getenv("ORBX_BLUR_LOGW")) h->blurLogW = atoi(e);
     if (const char* e = getenv("ORBX_NPIPES")) h->maxPipes = std::min(std::max(atoi(e), 1), ORBX_PIPES);
     if (const char* e = getenv("ORBX_FORK_BLUR")) h->forkBlur = atoi(e) != 0;
     if (const char* e = getenv("ORBX_BLUR_LDS")) h->blurLds = std::min(std::max(atoi(e), 0), 65536);
@@ -2541,10 +2716,50 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             // blockIdx.x counts from the first level's item base
             Geom gs = g;
             for (int l = first; l < g.nlevels; l++) gs.lv[l].blurItemBase -= itemBegin;
-            dim3 grid(n, (g.totalBlurItems - itemBegin + 255) / 256, 1), block(256, 1, 1);
-            auto kb = h->cfg.blur_variant == 2 ? k_blur_stream<true> : k_blur_stream<false>;
-            hipLaunchKernelGGL(kb, grid, block, h->blurLds, bst, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
-                               h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
+            // lane offsets are 32-bit: K frames of either image must stay below 2^31 bytes
+            const bool rowsOk = h->blurRows && (u64)img0.frameStride * 64 < 0x7FFFFFFFull && (u64)g.pyrFrameBytes * 64 < 0x7FFFFFFFull &&
+                                (u64)g.blurFrameBytes * 64 < 0x7FFFFFFFull;
+            if (rowsOk) {
+                // one lane split (W column groups x 64 / W frames) for all levels: the one with the fewest idle lanes
+                BlurRowsArgs A;
+                memset(&A, 0, sizeof(A));
+                // (64 x 1 or 32 x 2: narrower rows per frame cost more in the memory pipeline than idle lanes do,
+                // 0.58 and 0.81 us per frame at 16 x 4 and 8 x 8 against 0.51 at 32 x 2 for 640x480)
+                double bestEff = -1;
+                for (int lw = 6; lw >= 5; lw--) {
+                    const int Wd = 1 << lw, K = 64 >> lw;
+                    double used = 0, slots = 0;
+                    for (int l = first; l < g.nlevels; l++) {
+                        if (g.lv[l].h < 4 || g.lv[l].w < 4) continue;
+                        used += (double)g.lv[l].blurGroups * g.lv[l].h * n;
+                        slots += (double)((g.lv[l].blurGroups + Wd - 1) / Wd) * Wd * g.lv[l].h * ((n + K - 1) / K) * K;
+                    }
+                    const double eff = slots > 0 ? used / slots : 0;
+                    if (eff > bestEff + 1e-9) {
+                        bestEff = eff;
+                        A.logW = lw;
+                    }
+                }
+                if (h->blurLogW >= 3 && h->blurLogW <= 6) A.logW = h->blurLogW;
+                const int Wd = 1 << A.logW, K = 64 >> A.logW;
+                int tasks = 0;
+                for (int l = 0; l < g.nlevels; l++) {
+                    A.taskBase[l] = tasks;
+                    A.chunks[l] = std::max((g.lv[l].blurGroups + Wd - 1) / Wd, 1);
+                    if (l >= first && g.lv[l].h >= 4 && g.lv[l].w >= 4) tasks += A.chunks[l] * g.lv[l].blurBands;
+                }
+                A.taskBase[g.nlevels] = tasks;
+                A.firstLevel = first;
+                dim3 grid((n + K - 1) / K, (tasks + 3) / 4, 1), block(256, 1, 1);
+                auto kb = h->cfg.blur_variant == 2 ? k_blur_rows<true> : k_blur_rows<false>;
+                hipLaunchKernelGGL(kb, grid, block, h->blurLds, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0], h->gaussK[1],
+                                   h->gaussK[2], h->gaussK[3], A, n);
+            } else {
+                dim3 grid(n, (g.totalBlurItems - itemBegin + 255) / 256, 1), block(256, 1, 1);
+                auto kb = h->cfg.blur_variant == 2 ? k_blur_stream<true> : k_blur_stream<false>;
+                hipLaunchKernelGGL(kb, grid, block, h->blurLds, bst, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                                   h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
+            }
         }
     }
     if (fork) {
