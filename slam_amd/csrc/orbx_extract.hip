@@ -1345,7 +1345,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                                                    int* errFlag, unsigned char* nodeTables, size_t nodeTableStride) {
     extern __shared__ __align__(16) unsigned char smemLds[];
     __shared__ QtShared S;
-    const int l = blockIdx.x, f = blockIdx.y;
+    // Workgroups are dispatched in linear order: with the level as the slow index all workgroups of the
+    // large levels start first and the small levels fill the end of the launch, instead of every round
+    // of resident workgroups lasting as long as its level-0 members.
+    const int l = blockIdx.y, f = blockIdx.x;
     const LevelGeom& LG = g.lv[l];
     const int tid = threadIdx.x;
     const int lcap = LG.lcap;
@@ -2775,7 +2778,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     }
     {
         StageTimer t(h, ORBX_STAGE_QUADTREE);
-        dim3 grid(g.nlevels, n, 1), block(h->qtThreads, 1, 1);
+        dim3 grid(n, g.nlevels, 1), block(h->qtThreads, 1, 1);
         if (h->qtGlobal) {
             // node tables in global memory: one slice per (frame, level) of this pass
             hipLaunchKernelGGL((k_quadtree<1024, true>), grid, dim3(1024, 1, 1), 0, st, g, (const u32*)h->dCellCount,
