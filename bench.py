@@ -36,7 +36,7 @@ ALG_BYTES = {
     "quadtree": None,                                   # latency-bound list logic; bytes are negligible
 }
 KERNEL_OF = {"pyramid": "k_pyramid_frame", "fast": "k_fast", "quadtree": "k_quadtree",
-             "blur": "k_blur_stream", "describe": "k_describe"}
+             "blur": "k_blur_rows", "describe": "k_describe"}
 
 
 def parse():

@@ -16,7 +16,7 @@ full = os.path.join(src, "stats", "s_kernel_stats.csv")
 if os.path.exists(full):
     shutil.copy(full, os.path.join("profiles", "%s_rocprofv3_kernel_stats_full.csv" % tag))
 summ = json.load(open(os.path.join(src, "summary_%s.json" % tag)))
-stage_of = {"k_fast": "fast", "k_quadtree": "quadtree", "k_blur_stream": "blur", "k_describe": "describe",
+stage_of = {"k_fast": "fast", "k_quadtree": "quadtree", "k_blur_stream": "blur", "k_blur_rows": "blur", "k_describe": "describe",
             "k_resize_stream": "pyramid", "k_pyramid_frame": "pyramid"}
 out = {}
 for k, t in summ["traffic"].items():
