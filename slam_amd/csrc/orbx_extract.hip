@@ -102,6 +102,19 @@ __device__ __forceinline__ u32 as_u32(u16x2 v) {
     return r;
 }
 
+// A load from a table that no kernel writes (the host fills it before the first launch), through the
+// constant address space: the compiler may then fetch it through the scalar cache whenever the address
+// is wave-uniform, without having to prove that none of the kernel's stores reaches it (a proof it
+// gives up on as a kernel grows).
+template <typename T>
+__device__ __forceinline__ T load_table(const void* p) {
+#if __HIP_DEVICE_COMPILE__
+    return *(const __attribute__((address_space(4))) T*)(uintptr_t)p;
+#else
+    return *(const T*)p;  // the host pass of the compiler only parses this
+#endif
+}
+
 // ------------------------------------------------------------------ resize
 struct ResizeTap {
     u16 i0, i1;  // source indices (already clamped)
@@ -311,13 +324,17 @@ __device__ __forceinline__ void resize_walk(const ResizeLane& L, const __amdgpu_
         for (int k = 0; k < RESIZE_PF; k++) {
             const int sr = min(s0 + k, sh - 1);
             g.raw[k] = __builtin_amdgcn_raw_buffer_load_b64(srcRs, (int)L.offS, sr * srcPitch, 0);
-            g.tab[k] = *(const uint4*)(st + 2 * sr);
+            g.tab[k] = load_table<uint4>(st + 2 * sr);
         }
     };
     // st[2 * s + e], e = 0, 1: the destination rows whose second tap is source row s, as
     // {i0 = destination row or 0xFFFF, i1 = 1 when both taps are row s, c0, c1}
-    int s = yt[y0].i0;                // first source row of the band
-    const int sLast = yt[y1 - 1].i1;  // last one
+    // the band is the same for every lane: saying so keeps the row walk in scalar registers whatever
+    // divergent code surrounds the call
+    y0 = __builtin_amdgcn_readfirstlane(y0);
+    y1 = __builtin_amdgcn_readfirstlane(y1);
+    int s = __builtin_amdgcn_readfirstlane((int)load_table<ResizeTap>(yt + y0).i0);                // first source row of the band
+    const int sLast = __builtin_amdgcn_readfirstlane((int)load_table<ResizeTap>(yt + y1 - 1).i1);  // last one
     u32 prev[4] = {0, 0, 0, 0}, cur[4];
     u32 two = 2;
     asm volatile("" : "+v"(two));  // a vector register for the byte-inserting shifts below
@@ -414,6 +431,8 @@ __global__ __launch_bounds__(256) void k_resize_rows(ImgRef src, int sw, int sh,
 // and a level is read back while it is still in the caches.
 struct PyramidLevel {
     int sw, sh, dw, dh, srcPitch, dstPitch, chunks;
+    int stripGroups;     // column groups past the last full chunk, done as a block of rows per wave step (0: none)
+    int stripLogW;       // log2 of the lanes a row of that block takes
     u32 srcOff, dstOff;  // byte offsets of the two levels inside a frame of the pyramid buffer
     const ResizeTap *xt, *yt, *st;
 };
@@ -421,6 +440,7 @@ struct PyramidArgs {
     PyramidLevel lv[ORBX_MAX_LEVELS];
 };
 #define PYR_WAVES 16
+#define PYR_STRIP_MAX 16  // widest remainder (column groups) that is done as a block of rows instead of a chunk of walks
 __global__ __launch_bounds__(64 * PYR_WAVES, 8) void k_pyramid_frame(ImgRef img0, u8* pyr, i64 pyrFrameBytes, int imgBytes,
                                                                      PyramidArgs args, int nlevels) {
     const int lane = threadIdx.x & 63;
@@ -444,10 +464,42 @@ __global__ __launch_bounds__(64 * PYR_WAVES, 8) void k_pyramid_frame(ImgRef img0
         const __amdgpu_buffer_rsrc_t dstRs =
             __builtin_amdgcn_make_buffer_rsrc((void*)(frame + A.dstOff), 0, (int)(A.dh * A.dstPitch), 0x00020000);
         const int G = (A.dw + 3) >> 2;
+        const int Gwalk = A.stripGroups > 0 ? A.chunks * 64 : G;  // groups covered by the row walks
         const int chunk = wave % A.chunks, idx = wave / A.chunks;
         const int nw = (PYR_WAVES - chunk + A.chunks - 1) / A.chunks;  // waves on this chunk
         const int y0 = (int)((i64)idx * A.dh / nw), y1 = (int)((i64)(idx + 1) * A.dh / nw);
-        if (chunk * 64 + lane < G && y1 > y0) resize_walk(L, srcRs, dstRs, A.srcPitch, A.dstPitch, A.sh, A.yt, A.st, y0, y1);
+        if (chunk * 64 + lane < Gwalk && y1 > y0) resize_walk(L, srcRs, dstRs, A.srcPitch, A.dstPitch, A.sh, A.yt, A.st, y0, y1);
+        // A few column groups past the last full chunk would cost a chunk's worth of row walks for a handful
+        // of lanes (a walk takes the same time whatever the number of active lanes).  They are done as a
+        // block instead: a wave's lanes are Wp column groups (the remainder rounded up to a power of two)
+        // x 64 / Wp consecutive destination rows, each lane fetching the windows of its own two source
+        // rows; same arithmetic, no carried row sums, and a step still touches few cache lines.
+        if (A.stripGroups > 0) {
+            const int logWp = A.stripLogW, R = 64 >> logWp;
+            const int k = lane & ((1 << logWp) - 1), r = lane >> logWp;
+            const int steps = (A.dh + R - 1) / R;
+            if (PYR_WAVES - 1 - wave < steps && k < A.stripGroups) {
+                const ResizeLane S = resize_lane(A.xt, A.chunks * 64 + k, A.dw, A.sw, 0u, 0u);
+                for (int stp = PYR_WAVES - 1 - wave; stp < steps; stp += PYR_WAVES) {
+                    const int y = stp * R + r;
+                    if (y < A.dh) {
+                        const ResizeTap ty = A.yt[y];
+                        typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+                        const u32x2 r0 = __builtin_amdgcn_raw_buffer_load_b64(srcRs, (int)(S.offS + (u32)ty.i0 * (u32)A.srcPitch), 0, 0);
+                        const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(srcRs, (int)(S.offS + (u32)ty.i1 * (u32)A.srcPitch), 0, 0);
+                        const u32 b0 = (u32)(u16)ty.c0 << 16, b1 = (u32)(u16)ty.c1 << 16;
+                        u32 out = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const u32 t0 = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(r0[1], r0[0], S.sel[j])), as_u16x2(S.coef[j]), 0u, false) >> 4;
+                            const u32 t1 = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(r1[1], r1[0], S.sel[j])), as_u16x2(S.coef[j]), 0u, false) >> 4;
+                            out |= ((__umulhi(b0, t0) + __umulhi(b1, t1) + 2u) >> 2) << (8 * j);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(out, dstRs, (int)(S.offD + (u32)y * (u32)A.dstPitch), 0, 0);
+                    }
+                }
+            }
+        }
         // the next level's column taps do not depend on this level's pixels: fetched while the frame's other waves finish
         if (l + 1 < nlevels) L = lane_setup(l + 1);
         __syncthreads();  // waits for this wave's stores, then for every wave of the frame
@@ -2464,7 +2516,19 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         A.dstPitch = g.lv[l].pyrPitch;
         A.srcOff = l > 1 ? (u32)g.lv[l - 1].pyrOff : 0u;
         A.dstOff = (u32)g.lv[l].pyrOff;
-        A.chunks = ((A.dw + 3) / 4 + 63) / 64;
+        {
+            const int G = (A.dw + 3) / 4, full = G / 64, rem = G % 64;
+            A.chunks = (G + 63) / 64;
+            A.stripGroups = 0;
+            A.stripLogW = 0;
+            static const int stripMax = getenv("ORBX_PYR_STRIP") ? atoi(getenv("ORBX_PYR_STRIP")) : PYR_STRIP_MAX;
+            if (full >= 1 && rem > 0 && rem <= min(stripMax, 64)) {  // a thin remainder: blocks of rows instead of a chunk of walks
+                A.chunks = full;
+                A.stripGroups = rem;
+                A.stripLogW = 0;
+                while ((1 << A.stripLogW) < rem) A.stripLogW++;
+            }
+        }
         A.xt = h->dTaps + h->tapXOff[l];
         A.yt = h->dTaps + h->tapYOff[l];
         A.st = h->dTaps + h->tapSOff[l];
