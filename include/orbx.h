@@ -454,6 +454,21 @@ typedef struct orbm_bow_job {
 int orbm_search_by_bow_batch(orbm_context* m, orbm_bow_job* jobs, int njobs, int max_dist, float nn_ratio,
                              int check_orientation);
 
+/* Many independent SearchForInitialization calls in one set of launches (reference
+ * src/ORBmatcher.cc:497-617, one call per initialisation attempt at src/Tracking.cc:744; many sequences
+ * or many candidate second frames at once here): orbm_search_for_initialization for every entry of
+ * `jobs` with shared window_size, nn_ratio and check_orientation.  Every array a job points to is
+ * DEVICE memory (the job table itself is host memory); prev_matched_xy (2 * f1.n floats) is in/out,
+ * matches12 (f1.n) is an output, nmatches is written on return. */
+typedef struct orbm_init_job {
+    orbm_frame f1, f2;
+    float* prev_matched_xy; /* 2 * f1.n, in/out */
+    int32_t* matches12;     /* f1.n, out */
+    int32_t nmatches;       /* out */
+} orbm_init_job;
+int orbm_search_for_initialization_batch(orbm_context* m, orbm_init_job* jobs, int njobs, int window_size,
+                                         float nn_ratio, int check_orientation);
+
 /* Many independent projected searches in one call: orbm_search_projected for every entry of `jobs`
  * under one policy, i.e. the batched form of the three SearchByProjection overloads that project map
  * points into a frame or keyframe (reference src/ORBmatcher.cc:62-164, :370-485, :1694-1836; the

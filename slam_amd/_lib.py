@@ -81,6 +81,11 @@ class BowJob(C.Structure):
                 ("valid2", C.c_void_p), ("match12", C.c_void_p), ("match21", C.c_void_p), ("nmatches", C.c_int32)]
 
 
+class InitJob(C.Structure):
+    _fields_ = [("f1", MFrame), ("f2", MFrame), ("prev_matched_xy", C.c_void_p), ("matches12", C.c_void_p),
+                ("nmatches", C.c_int32)]
+
+
 # Every exported symbol of include/orbx.h: (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -147,6 +152,7 @@ SIGNATURES = {
                                          C.POINTER(Pyramid), _vp, _vp, _f, _f, _vp, _vp, _vp, _i]),
     "orbm_search_by_projection_batch": (_i, [_vp, C.POINTER(ProjectionPair), _i, _vp, _i, _f, _f, _i]),
     "orbm_search_by_bow_batch": (_i, [_vp, C.POINTER(BowJob), _i, _i, _f, _i]),
+    "orbm_search_for_initialization_batch": (_i, [_vp, C.POINTER(InitJob), _i, _i, _f, _i]),
     "orbm_search_projected_batch": (_i, [_vp, C.POINTER(ProjectedJob), _i, C.POINTER(ProjPolicy), _f]),
     "orbm_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i]),
     "orbm_bow_transform": (_i, [_vp, C.POINTER(Vocabulary), _vp, _i, _i, _vp, _vp, _vp, _i]),

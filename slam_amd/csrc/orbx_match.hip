@@ -669,6 +669,10 @@ struct ProjJob {
     u8* qValid;
     float *qRadius, *qAngle, *qUR;
     int *qMin, *qMax;
+    // SearchForInitialization over a table of pairs (reference src/ORBmatcher.cc:497-617)
+    float* initPrev;                 // vbPrevMatched as x, y pairs, read and updated
+    float *initU, *initV;            // the same, split, as the candidate walk wants its queries
+    int* initM21;                    // vnMatches21 of the wave-per-pair form
 };
 
 __global__ __launch_bounds__(1024) void k_grid_build(DevFrame f, int* cellStart, int* cellItems, u16* cellOf) {
@@ -977,10 +981,10 @@ __global__ __launch_bounds__(64) void k_projq_resolve_jobs(const ProjJob* __rest
 // Sequential part (reference src/ORBmatcher.cc:515-591): one wave, queries in
 // index order; vMatchedDistance / vnMatches21 / vnMatches12 live in global
 // scratch written and read by this wave only.
-__global__ __launch_bounds__(64) void k_init_resolve(DevFrame f1, DevFrame f2, const int* __restrict__ offs,
-                                                       const int* __restrict__ candIdx, const int* __restrict__ candDist,
-                                                       float nnRatio, int checkOri, int* matchedDist, int* matches21,
-                                                       int* matches12, int* qBin, float* prevMatched, int* nmatchesOut) {
+__device__ __forceinline__ void init_resolve_body(DevFrame f1, DevFrame f2, const int* __restrict__ offs,
+                                                  const int* __restrict__ candIdx, const int* __restrict__ candDist,
+                                                  float nnRatio, int checkOri, int* matchedDist, int* matches21,
+                                                  int* matches12, int* qBin, float* prevMatched, int* nmatchesOut) {
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int keep[3];
     const int lane = threadIdx.x;
@@ -1073,13 +1077,20 @@ __global__ __launch_bounds__(64) void k_init_resolve(DevFrame f1, DevFrame f2, c
     }
     if (lane == 0) *nmatchesOut = nmatches;
 }
+__global__ __launch_bounds__(64) void k_init_resolve(DevFrame f1, DevFrame f2, const int* __restrict__ offs,
+                                                       const int* __restrict__ candIdx, const int* __restrict__ candDist,
+                                                       float nnRatio, int checkOri, int* matchedDist, int* matches21,
+                                                       int* matches12, int* qBin, float* prevMatched, int* nmatchesOut) {
+    init_resolve_body(f1, f2, offs, candIdx, candDist, nnRatio, checkOri, matchedDist, matches21, matches12, qBin, prevMatched,
+                      nmatchesOut);
+}
 
 // Candidate rows sorted by (distance, position in the row): sorted[b + rank] = distance << 16 | index.
 // One wave per query; the rank of an entry is the number of smaller keys in its row (keys are unique).
 // With a row in this order the reference's scan (src/ORBmatcher.cc:529-548) reads off its result from
 // the front: the best is the first admissible entry, the second-best distance that of the next one.
-__global__ __launch_bounds__(256) void k_sort_rows(const int* __restrict__ offs, const int* __restrict__ candIdx,
-                                                    const int* __restrict__ candDist, u32* __restrict__ sorted, int nq) {
+__device__ __forceinline__ void sort_rows_body(const int* __restrict__ offs, const int* __restrict__ candIdx,
+                                               const int* __restrict__ candDist, u32* __restrict__ sorted, int nq) {
     __shared__ u32 rows[4][1024];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
@@ -1110,16 +1121,19 @@ __global__ __launch_bounds__(256) void k_sort_rows(const int* __restrict__ offs,
         if (j < n) sorted[b + rank] = (myKey & 0xFFFF0000u) | (u32)candIdx[b + j];
     }
 }
+__global__ __launch_bounds__(256) void k_sort_rows(const int* __restrict__ offs, const int* __restrict__ candIdx,
+                                                    const int* __restrict__ candDist, u32* __restrict__ sorted, int nq) {
+    sort_rows_body(offs, candIdx, candDist, sorted, nq);
+}
 
 // SearchForInitialization's sequential part over sorted rows, all state in LDS, 64 queries at a time
 // (one per lane).  A match only lowers vMatchedDistance of its target, i.e. removes that target from
 // later queries' lists, so a query depends on earlier uncommitted ones only through its best and
 // second-best entries: a lane whose best or second is wanted by an earlier pending lane waits a round,
 // all pending lanes below the lowest such lane commit together, and the result is that of the serial loop.
-__global__ __launch_bounds__(256) void k_init_resolve_sorted(DevFrame f1, DevFrame f2, const int* __restrict__ offs,
-                                                              const u32* __restrict__ sorted, float nnRatio, int checkOri,
-                                                              int* matches12, float* prevMatched, int* nmatchesOut) {
-    extern __shared__ __align__(16) u8 ism[];
+__device__ __forceinline__ void init_resolve_sorted_body(u8* ism, DevFrame f1, DevFrame f2, const int* __restrict__ offs,
+                                                         const u32* __restrict__ sorted, float nnRatio, int checkOri,
+                                                         int* matches12, float* prevMatched, int* nmatchesOut) {
     __shared__ int hist[HISTO_LENGTH];
     __shared__ int keep[3];
     __shared__ int counters[2];
@@ -1243,6 +1257,39 @@ __global__ __launch_bounds__(256) void k_init_resolve_sorted(DevFrame f1, DevFra
         }
     }
     if (tid == 0) *nmatchesOut = counters[0] - counters[1];
+}
+__global__ __launch_bounds__(256) void k_init_resolve_sorted(DevFrame f1, DevFrame f2, const int* __restrict__ offs,
+                                                              const u32* __restrict__ sorted, float nnRatio, int checkOri,
+                                                              int* matches12, float* prevMatched, int* nmatchesOut) {
+    extern __shared__ __align__(16) u8 ism[];
+    init_resolve_sorted_body(ism, f1, f2, offs, sorted, nnRatio, checkOri, matches12, prevMatched, nmatchesOut);
+}
+
+// The same over a table of independent frame pairs: `last` is F1 (the queries), `train` is F2.
+__global__ void k_init_queries_jobs(const ProjJob* __restrict__ jobs, float window) {
+    const ProjJob& J = jobs[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= J.last.n) return;
+    J.qValid[i] = J.last.kps[i].octave <= 0 ? 1 : 0;
+    J.initU[i] = J.initPrev[2 * i];
+    J.initV[i] = J.initPrev[2 * i + 1];
+    J.qRadius[i] = window;
+    J.qMin[i] = 0;
+    J.qMax[i] = 0;
+}
+__global__ __launch_bounds__(256) void k_sort_rows_jobs(const ProjJob* __restrict__ jobs) {
+    const ProjJob& J = jobs[blockIdx.y];
+    sort_rows_body(J.offs, J.candIdx, J.candDist, J.slab, J.q.n);
+}
+__global__ __launch_bounds__(256) void k_init_resolve_sorted_jobs(const ProjJob* __restrict__ jobs, float nnRatio, int checkOri) {
+    extern __shared__ __align__(16) u8 ism[];
+    const ProjJob& J = jobs[blockIdx.x];
+    init_resolve_sorted_body(ism, J.last, J.train, J.offs, J.slab, nnRatio, checkOri, J.qBest, J.initPrev, J.nmatches);
+}
+__global__ __launch_bounds__(64) void k_init_resolve_jobs(const ProjJob* __restrict__ jobs, float nnRatio, int checkOri) {
+    const ProjJob& J = jobs[blockIdx.x];
+    init_resolve_body(J.last, J.train, J.offs, J.candIdx, J.candDist, nnRatio, checkOri, J.claimed, J.initM21, J.qBest, J.qBin,
+                      J.initPrev, J.nmatches);
 }
 
 // Queries of SearchForInitialization: level-0 keypoints of F1 search a window
@@ -2499,7 +2546,7 @@ struct orbm_context {
     // grow-only scratch, one block per purpose
     std::vector<std::pair<void*, size_t>> pool;
     std::vector<int> totalsHost;
-    bool resolveLdsReady = false, resolveJobsLdsReady = false, initSortedReady = false, distinctiveReady = false;
+    bool resolveLdsReady = false, resolveJobsLdsReady = false, initSortedReady = false, initSortedJobsReady = false, distinctiveReady = false;
     int knnPath = 0;  // 0 = by size, 1 = vector ALU, 2 = matrix cores (orbm_debug_knn_path)  // the LDS form of the sequential resolve has had its dynamic LDS limit raised
     // Host arrays travel through one pinned arena per call: copies from and to pageable memory are staged
     // and serialised by the runtime (10-15 us each), copies from pinned memory are plain queue entries.
@@ -3466,6 +3513,136 @@ int orbm_search_projected_batch(orbm_context* m, orbm_projected_job* jobsIn, int
     if ((rc = run_projection_jobs(m, jobs, dJobs, njobs, maxNq, pol, false, nullptr, 0.f, window_hint > 0.f ? window_hint : 1e9f,
                                   dTot, dOverflow, nmArr)))
         return rc;
+    for (int i = 0; i < njobs; i++) jobsIn[i].nmatches = m->totalsHost[i];
+    return ORBX_OK;
+}
+
+int orbm_search_for_initialization_batch(orbm_context* m, orbm_init_job* jobsIn, int njobs, int window_size, float nn_ratio,
+                                         int check_orientation) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (njobs < 0 || (njobs > 0 && !jobsIn)) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (njobs == 0) return ORBX_OK;
+    size_t words = 0, bytes = 0;
+    int maxN1 = 0;
+    for (int i = 0; i < njobs; i++) {
+        const orbm_init_job& P = jobsIn[i];
+        if (P.f1.n < 0 || P.f2.n < 0 || P.f1.n > 65000 || P.f2.n > 65000 ||
+            (P.f1.n > 0 && (!P.f1.kps || !P.f1.desc || !P.prev_matched_xy || !P.matches12)) ||
+            (P.f2.n > 0 && (!P.f2.kps || !P.f2.desc))) {
+            orbx_set_error("job %d: invalid argument", i);
+            return ORBX_ERR_INVALID;
+        }
+        const size_t n1 = (size_t)P.f1.n, n2 = (size_t)P.f2.n;
+        // cellStart, cellItems, counts, offs, qMin, qMax, qBin, u, v, radius, vMatchedDistance, vnMatches21, nmatches
+        words += (GRID_CELLS + 1) + n2 + n1 + (n1 + 1) + 6 * n1 + 2 * n2 + 1 + 8;
+        bytes += 2 * n2 + n1 + 32;  // cellOf, qValid
+        maxN1 = std::max(maxN1, P.f1.n);
+    }
+    void *dJobs, *dWords, *dBytes, *dTot;
+    if ((rc = pool_get(m, SL_JB_JOBS, (size_t)njobs * sizeof(ProjJob), &dJobs)) ||
+        (rc = pool_get(m, SL_JB_I32, words * 4, &dWords)) || (rc = pool_get(m, SL_JB_U8, bytes, &dBytes)) ||
+        (rc = pool_get(m, SL_JB_TOT, ((size_t)njobs * 2 + 8) * sizeof(int), &dTot)))
+        return rc;
+    ProjJob* jobs = (ProjJob*)arena_alloc(m, (size_t)njobs * sizeof(ProjJob));
+    if (!jobs) return ORBX_ERR_HIP;
+    int* wp = (int*)dWords;
+    u8* bp = (u8*)dBytes;
+    int* nmArr = (int*)dTot + njobs;
+    for (int i = 0; i < njobs; i++) {
+        const orbm_init_job& P = jobsIn[i];
+        ProjJob& J = jobs[i];
+        memset(&J, 0, sizeof(J));
+        if ((rc = make_frame(m, &P.f2, 0, 0, ORBX_MEM_DEVICE, &J.train))) return rc;
+        if ((rc = make_frame(m, &P.f1, 0, 0, ORBX_MEM_DEVICE, &J.last))) return rc;
+        const size_t n1 = (size_t)P.f1.n, n2 = (size_t)P.f2.n;
+        auto takeW = [&](size_t n) {
+            int* r = wp;
+            wp += n;
+            return r;
+        };
+        J.cellStart = takeW(GRID_CELLS + 1);
+        J.cellItems = takeW(n2);
+        J.counts = takeW(n1);
+        J.offs = takeW(n1 + 1);
+        J.qMin = takeW(n1);
+        J.qMax = takeW(n1);
+        J.qBin = takeW(n1);
+        J.initU = (float*)takeW(n1);
+        J.initV = (float*)takeW(n1);
+        J.qRadius = (float*)takeW(n1);
+        J.claimed = takeW(n2);  // vMatchedDistance of the wave-per-pair form
+        J.initM21 = takeW(n2);
+        wp += 8;
+        J.cellOf = (u16*)bp;
+        bp += 2 * n2;
+        J.qValid = bp;
+        bp += n1;
+        bp = (u8*)(((uintptr_t)bp + 15) & ~(uintptr_t)15);
+        J.initPrev = P.prev_matched_xy;
+        J.qBest = (int*)P.matches12;
+        J.nmatches = nmArr + i;
+        J.q.n = P.f1.n;
+        J.q.valid = J.qValid;
+        J.q.u = J.initU;
+        J.q.v = J.initV;
+        J.q.radius = J.qRadius;
+        J.q.minLevel = J.qMin;
+        J.q.maxLevel = J.qMax;
+        J.q.desc = P.f1.desc;
+    }
+    const size_t jobBytes = (size_t)njobs * sizeof(ProjJob);
+    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
+    const ProjJob* dJ = (const ProjJob*)dJobs;
+    ORBM_LAUNCH(k_grid_build_jobs, dim3(njobs), dim3(1024), 0, m->stream, dJ);
+    if (maxN1 > 0) {
+        ORBM_LAUNCH(k_init_queries_jobs, dim3((maxN1 + 255) / 256, njobs), dim3(256), 0, m->stream, dJ, (float)window_size);
+        ORBM_LAUNCH(k_projq_candidates_jobs, dim3((maxN1 + 3) / 4, njobs), dim3(256), 0, m->stream, dJ, 0);
+    }
+    ORBM_LAUNCH(k_scan_jobs, dim3(njobs), dim3(1024), 0, m->stream, dJ, (int*)dTot);
+    ORBX_HIP_CHECK(hipGetLastError());
+    m->totalsHost.resize((size_t)njobs);
+    if ((rc = d2h(m, m->totalsHost.data(), dTot, (size_t)njobs * sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
+    size_t total = 0, maxLds = 0;
+    bool fits = true;
+    for (int i = 0; i < njobs; i++) {
+        total += (size_t)m->totalsHost[i];
+        const size_t n1 = (size_t)jobsIn[i].f1.n, n2 = (size_t)std::max(jobsIn[i].f2.n, 1);
+        maxLds = std::max(maxLds, n2 * 12 + n1 * 8 + 16);
+    }
+    fits = maxLds <= 150 * 1024;
+    void *cIdx, *cDist, *srt;
+    if ((rc = pool_get(m, SL_CAND_IDX, std::max(total, (size_t)1) * 4, &cIdx)) ||
+        (rc = pool_get(m, SL_CAND_DIST, std::max(total, (size_t)1) * 4, &cDist)) ||
+        (rc = pool_get(m, SL_SORTED, std::max(total, (size_t)1) * 4, &srt)))
+        return rc;
+    size_t off = 0;
+    for (int i = 0; i < njobs; i++) {
+        jobs[i].candIdx = (int*)cIdx + off;
+        jobs[i].candDist = (int*)cDist + off;
+        jobs[i].slab = (u32*)srt + off;  // the rows again, sorted by distance
+        off += (size_t)m->totalsHost[i];
+    }
+    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, jobBytes, hipMemcpyHostToDevice, m->stream));
+    if (maxN1 > 0) ORBM_LAUNCH(k_projq_candidates_jobs, dim3((maxN1 + 3) / 4, njobs), dim3(256), 0, m->stream, dJ, 2);
+    if (fits) {
+        if (!m->initSortedJobsReady) {
+            ORBX_HIP_CHECK(hipFuncSetAttribute((const void*)k_init_resolve_sorted_jobs, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               150 * 1024));
+            m->initSortedJobsReady = true;
+        }
+        if (maxN1 > 0) ORBM_LAUNCH(k_sort_rows_jobs, dim3((maxN1 + 3) / 4, njobs), dim3(256), 0, m->stream, dJ);
+        ORBM_LAUNCH(k_init_resolve_sorted_jobs, dim3(njobs), dim3(256), maxLds, m->stream, dJ, nn_ratio, check_orientation);
+    } else {
+        ORBM_LAUNCH(k_init_resolve_jobs, dim3(njobs), dim3(64), 0, m->stream, dJ, nn_ratio, check_orientation);
+    }
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = d2h(m, m->totalsHost.data(), nmArr, (size_t)njobs * sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
     for (int i = 0; i < njobs; i++) jobsIn[i].nmatches = m->totalsHost[i];
     return ORBX_OK;
 }

@@ -105,6 +105,21 @@ class ORBmatcher:
             int(windowSize), self.mfNNratio, int(self.mbCheckOrientation), C.byref(n), MEM_HOST))
         return n.value, m12[:F1.N].copy(), pm
 
+    def SearchForInitializationBatch(self, jobs, windowSize=10):
+        """SearchForInitialization for many independent frame pairs in one set of launches (device-resident).
+        `jobs`: list of dicts of torch DEVICE tensors: kps1 (n1, 28) u8, desc1 (n1, 32) u8, kps2, desc2,
+        bounds (4 floats), prev_matched (n1, 2) f32 (in/out), matches12 i32 (n1, out).  Returns the list
+        of match counts."""
+        arr = (_lib.InitJob * len(jobs))()
+        for i, p in enumerate(jobs):
+            arr[i].f1 = MFrame(p["kps1"].data_ptr(), p["desc1"].data_ptr(), p["kps1"].shape[0], *p["bounds"])
+            arr[i].f2 = MFrame(p["kps2"].data_ptr(), p["desc2"].data_ptr(), p["kps2"].shape[0], *p["bounds"])
+            arr[i].prev_matched_xy = p["prev_matched"].data_ptr()
+            arr[i].matches12 = p["matches12"].data_ptr()
+        check(self._lib.orbm_search_for_initialization_batch(self._m, arr, len(arr), int(windowSize), float(self.mfNNratio),
+                                                             int(self.mbCheckOrientation)))
+        return [arr[i].nmatches for i in range(len(arr))]
+
     # ---- projected searches
     def _claims(self, n, claimed, claimed_obs):
         cl = np.full(max(n, 1), -1, np.int32) if claimed is None else np.array(claimed, np.int32)

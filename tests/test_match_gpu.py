@@ -114,6 +114,109 @@ def test_search_for_initialization(oracle, frames, ratio, ori, window):
     m.close()
 
 
+@pytest.mark.parametrize("ratio,ori,window", [(0.9, True, 100), (0.7, False, 30)])
+def test_search_for_initialization_batch_equals_oracle_per_job(oracle, frames, ratio, ori, window):
+    """SearchForInitialization for many independent pairs in one call (device-resident): every job equals the
+    oracle's result for that job: both directions of the pair, perturbed previous matches, an empty first frame,
+    an empty second frame, a truncated pair; then the second call from the updated positions."""
+    import torch
+    from slam_amd.matcher import ORBmatcher
+    (ka, da), (kb, db) = frames["a"], frames["b"]
+    sf = frames["sf"]
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    raw = lambda k: k.view(np.uint8).reshape(-1, 28)  # noqa: E731
+    specs = []
+    for i in range(7):
+        rng = np.random.RandomState(60 + i)
+        k1, d1, k2, d2 = (ka, da, kb, db) if i % 2 == 0 else (kb, db, ka, da)
+        if i == 3:
+            k1, d1 = k1[:0], d1[:0]
+        if i == 4:
+            k2, d2 = k2[:0], d2[:0]
+        if i == 5:
+            k1, d1, k2, d2 = k1[:333], d1[:333], k2[100:900], d2[100:900]
+        prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+        if i >= 2:
+            prev = (prev + rng.normal(0, 4.0, prev.shape)).astype(np.float32)
+        specs.append((k1, d1, k2, d2, prev))
+    jobs = [dict(kps1=t(raw(k1)), desc1=t(d1), kps2=t(raw(k2)), desc2=t(d2), bounds=BOUNDS, prev_matched=t(prev),
+                 matches12=torch.full((max(len(k1), 1),), -7, dtype=torch.int32, device=dev))
+            for k1, d1, k2, d2, prev in specs]
+    m = ORBmatcher(ratio, ori)
+    try:
+        prevs = [s[4] for s in specs]
+        total = 0
+        for call in range(2):
+            counts = m.SearchForInitializationBatch(jobs, window)
+            torch.cuda.synchronize()
+            for j, (k1, d1, k2, d2, _) in enumerate(specs):
+                o1 = oracle.FrameData(k1, d1, BOUNDS, sf)
+                o2 = oracle.FrameData(k2, d2, BOUNDS, sf)
+                rn, rm12, rpm = oracle.search_for_initialization(o1, o2, prevs[j], window, ratio, ori)
+                assert counts[j] == rn, "call %d job %d" % (call, j)
+                assert np.array_equal(jobs[j]["matches12"].cpu().numpy()[:len(k1)], rm12[:len(k1)]), "call %d job %d" % (call, j)
+                assert np.array_equal(jobs[j]["prev_matched"].cpu().numpy().reshape(-1, 2), rpm.reshape(-1, 2))
+                prevs[j] = rpm.reshape(-1, 2).copy()
+                total += rn
+        assert total > 100
+        assert m.SearchForInitializationBatch([], window) == []
+    finally:
+        m.close()
+
+
+def test_search_for_initialization_batch_large_frames(oracle, frames):
+    """A pair whose claim state does not fit the LDS (12 000 keypoints in the second frame) sends the whole
+    batch through the wave-per-pair form; results still equal the oracle's per job."""
+    import torch
+    from slam_amd.matcher import ORBmatcher
+    (ka, da), (kb, db) = frames["a"], frames["b"]
+    sf = frames["sf"]
+    dev = "cuda"
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    raw = lambda k: k.view(np.uint8).reshape(-1, 28)  # noqa: E731
+    rng = np.random.RandomState(91)
+    n1, n2 = 1500, 12000
+    k1 = np.zeros(n1, ka.dtype)
+    k1["x"] = rng.uniform(5, 635, n1).astype(np.float32)
+    k1["y"] = rng.uniform(5, 475, n1).astype(np.float32)
+    k1["angle"] = rng.uniform(0, 360, n1).astype(np.float32)
+    k1["octave"] = (rng.uniform(size=n1) < 0.2).astype(np.int32)
+    d1 = synth.synth_descriptors(n1, 92)
+    k2 = np.zeros(n2, ka.dtype)
+    k2["x"] = rng.uniform(5, 635, n2).astype(np.float32)
+    k2["y"] = rng.uniform(5, 475, n2).astype(np.float32)
+    k2["angle"] = rng.uniform(0, 360, n2).astype(np.float32)
+    d2 = synth.synth_descriptors(n2, 93)
+    # the first 1200 keypoints of frame 2 are moved copies of frame 1's: a few flipped bits, a small rotation
+    m = 1200
+    k2["x"][:m] = k1["x"][:m] + rng.normal(0, 3, m).astype(np.float32)
+    k2["y"][:m] = k1["y"][:m] + rng.normal(0, 3, m).astype(np.float32)
+    k2["angle"][:m] = np.mod(k1["angle"][:m] + rng.normal(0, 4, m), 360).astype(np.float32)
+    d2[:m] = d1[:m]
+    flips = rng.randint(0, 256, size=(m, 12))
+    for j in range(m):
+        for b in flips[j][:rng.randint(0, 12)]:
+            d2[j, b >> 3] ^= np.uint8(1 << (b & 7))
+    specs = [(k1, d1, k2, d2), (ka, da, kb, db)]
+    prevs = [np.stack([a["x"], a["y"]], axis=1).astype(np.float32) for a, _, _, _ in specs]
+    jobs = [dict(kps1=t(raw(a)), desc1=t(b), kps2=t(raw(c)), desc2=t(d), bounds=BOUNDS, prev_matched=t(pv),
+                 matches12=torch.full((len(a),), -7, dtype=torch.int32, device=dev))
+            for (a, b, c, d), pv in zip(specs, prevs)]
+    mt = ORBmatcher(0.9, True)
+    try:
+        counts = mt.SearchForInitializationBatch(jobs, 20)
+        torch.cuda.synchronize()
+        for j, (a, b, c, d) in enumerate(specs):
+            rn, rm12, rpm = oracle.search_for_initialization(oracle.FrameData(a, b, BOUNDS, sf), oracle.FrameData(c, d, BOUNDS, sf),
+                                                             prevs[j], 20, 0.9, True)
+            assert counts[j] == rn and rn > 50, "job %d" % j
+            assert np.array_equal(jobs[j]["matches12"].cpu().numpy(), rm12)
+            assert np.array_equal(jobs[j]["prev_matched"].cpu().numpy().reshape(-1, 2), rpm.reshape(-1, 2))
+    finally:
+        mt.close()
+
+
 def projection_inputs(frames, seed, frac_no_obs=0.3, stereo=True):
     (ka, da), (kb, db) = frames["a"], frames["b"]
     rng = np.random.RandomState(seed)
