@@ -923,7 +923,9 @@ __host__ __device__ __forceinline__ u32 div_magic(u32 d) { return d <= 1 ? 0u : 
 //   w4 = gx0 | gy0 << 16 (detection-origin coordinates of the first interior pixel)
 //   w5 = magic(nWc)   w6 = magic(nk)   w7 = nWc | (64 / nWc) << 8
 //   w8 = byte offset of (iniY, iniX & ~3) inside the per-frame pyramid block (levels >= 1)
-//   w9 = row pitch of the level (levels >= 1)   w10 = magic(roi width)   w11 = 0
+//   w9 = row pitch of the level (levels >= 1)   w10 = magic(roi width)
+//   w11 = nFull | rem << 8: of the first 8 row groups of the ROI copy, groups below nFull hold a row
+//         for every copying lane and group nFull holds rem rows
 // nk = 32-bit words per row that hold interior pixels when interior pixel 0 sits on a word
 // boundary, nWc = nk + 2 = words copied per ROI row (one before, one after).
 struct FastCell {
@@ -972,6 +974,13 @@ __device__ unsigned long long* d_fastDiag;
 #define FAST_STAMP(i)
 #endif
 
+// The dynamic LDS array is the only LDS object of k_fast, so it starts at LDS address 0 and a byte
+// offset into it is an LDS address: reads through these forms take "register + immediate" with no
+// addition of the array's (zero) base.
+#define LDS_U8(a) (*(const __attribute__((address_space(3))) u8*)(size_t)(u32)(a))
+#define LDS_U32(a) (*(const __attribute__((address_space(3))) u32*)(size_t)(u32)(a))
+#define LDS_U32W(a) (*(__attribute__((address_space(3))) u32*)(size_t)(u32)(a))
+
 // One wave per cell.  The ROI goes to LDS with interior pixel 0 on a word boundary (byte 4 of
 // its row), then a cascade, all of it in raster order:
 //   1. a necessary condition for a FAST-9 corner on 4 pixels per lane: with u/d/l/r the ring
@@ -996,10 +1005,13 @@ struct __attribute__((packed, aligned(4))) FastPair {
     u32 a, b;
 };
 
+template <int RPC>
 __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligned, const u8* __restrict__ pyr,
                                               const FastCell* __restrict__ cells, u32* __restrict__ cellCount,
                                               u32* __restrict__ slots, int iniTh, int minTh) {
     extern __shared__ __align__(16) u8 lds[];
+    // LDS_U8 / LDS_U32 take offsets into this array as LDS addresses (resolved at compile time)
+    if ((u32)(size_t)(const __attribute__((address_space(3))) u8*)lds != 0u) __builtin_trap();
     u8* roi = lds;
     u8* plane = lds + g.fastPlaneOff;
     u32* wq = (u32*)plane;  // the word queue is dead before the plane is cleared
@@ -1009,7 +1021,9 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
     const int f = blockIdx.x;
     const int cell0 = blockIdx.y * FAST_CPW;
     const int lane = threadIdx.x;
-    const int RP = g.fastRoiPitch;
+    // RPC = the ROI row pitch as a compile-time constant (0: taken from the geometry): with a constant
+    // pitch every ring, neighbour and row access below is one base register plus an immediate offset
+    const int RP = RPC ? RPC : g.fastRoiPitch;
 #ifdef ORBX_FAST_DIAG
     unsigned long long diagT[5] = {0, 0, 0, 0, 0}, diagLast = __builtin_amdgcn_s_memtime();
     int diagN1 = 0, diagN2 = 0, diagPass2 = 0, diagNW = 0, diagTotal = 0;
@@ -1043,9 +1057,16 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
             const u8* sbase = source(C, &pitch);
             u32 soff = mul24((u32)lw, (u32)pitch) + 4u * (u32)wd;
             const u32 sStep = (u32)(rowsW * pitch);
+            // groups 0 .. nFull-1 hold a row for every copying lane, group nFull for lanes lw < rem: the
+            // first kind needs no per-lane test (wave-uniform branch)
+            const int nFull = (int)(C.w[11] & 255u), rem = (int)((C.w[11] >> 8) & 255u);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                if (lw + k * rowsW < rh) v[k] = *(const FastPair*)(sbase + soff);
+                if (k < nFull) {
+                    v[k] = *(const FastPair*)(sbase + soff);
+                } else if (k == nFull) {
+                    if (lw < rem) v[k] = *(const FastPair*)(sbase + soff);
+                }
                 soff += sStep;
             }
         }
@@ -1058,9 +1079,14 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
         if (lw < rowsW) {
             u32 doff = mul24((u32)lw, (u32)RP) + 4u * (u32)wd;
             const u32 dStep = (u32)(rowsW * RP);
+            const int nFull = (int)(C.w[11] & 255u), rem = (int)((C.w[11] >> 8) & 255u);
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                if (lw + k * rowsW < rh) *(u32*)(roi + doff) = __builtin_amdgcn_alignbyte(v[k].b, v[k].a, sh);
+                if (k < nFull) {
+                    LDS_U32W(doff) = __builtin_amdgcn_alignbyte(v[k].b, v[k].a, sh);
+                } else if (k == nFull) {
+                    if (lw < rem) LDS_U32W(doff) = __builtin_amdgcn_alignbyte(v[k].b, v[k].a, sh);
+                }
                 doff += dStep;
             }
             if (8 * rowsW < rh) {  // wave-uniform: cells taller than 8 groups
@@ -1127,7 +1153,6 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
         const u32 vmAll = (((1u << min(nv, 2)) - 1u) << 14) | (((1u << max(nv - 2, 0)) - 1u) << 30);
         const u32 vmE = vmAll & 0x40004000u, vmO = vmAll & 0x80008000u;
         const u32 entBase = mul24((u32)(lr + 3), (u32)RP) + 4u * (u32)(kk + 1);  // byte offset of the lane's word in the ROI
-        const u8* rcBase = roi + entBase;
         const int stepBytes = rowsPer * RP;
         // 16-byte units that cover plane rows 2 .. rh-3 (rows 0, 1 and the rows past rh-3 are never read;
         // the plane block holds fastRoiPitch * (tallest ROI) bytes, rounded up to 16)
@@ -1140,14 +1165,14 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
             const u32 K1 = k1 | (k1 << 16), K2 = k2 | (k2 << 16);
             int nW = 0;
             {
-                const u8* rp = rcBase;
+                u32 r0 = entBase - (u32)(3 * RP + 4);
                 u32 ent = entBase;
                 for (int yb = 0; yb < ih; yb += rowsPer) {
                     u32 m = 0;
                     if (laneOn && yb + lr < ih) {
-                        const u32* rc = (const u32*)rp;
-                        const u32 Cw = rc[0], Lw = rc[-1], Rw = rc[1];
-                        const u32 Uw = *(const u32*)((const u8*)rc - 3 * RP), Dw = *(const u32*)((const u8*)rc + 3 * RP);
+                        // r0 = lowest address read: the offsets are non-negative immediates
+                        const u32 Uw = LDS_U32(r0 + 4u), Lw = LDS_U32(r0 + (u32)(3 * RP)), Cw = LDS_U32(r0 + (u32)(3 * RP + 4));
+                        const u32 Rw = LDS_U32(r0 + (u32)(3 * RP + 8)), Dw = LDS_U32(r0 + (u32)(6 * RP + 4));
                         const u32 Rt = __builtin_amdgcn_alignbyte(Rw, Cw, 3);  // pixels x + 3
                         const u32 Lf = __builtin_amdgcn_alignbyte(Cw, Lw, 1);  // pixels x - 3
                         const u32 M = 0x00FF00FFu;
@@ -1172,7 +1197,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                     const int off = wave_excl_count(m != 0, &tot);
                     if (m != 0) wq[nW + off] = m | ent;
                     nW += tot;
-                    rp += stepBytes;
+                    r0 += (u32)stepBytes;
                     ent += (u32)stepBytes;
                 }
             }
@@ -1204,9 +1229,12 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                 const int ia = base + lane, ib = base + 64 + lane;
                 const bool okA = ia < n1, okB = ib < n1;
                 const u32 oa = okA ? (u32)queue[ia] : safe, ob = okB ? (u32)queue[ib] : safe;
-                const u8* pa = roi + oa;
-                const u8* pb = roi + ob;
-#define RING2(dx, dy) ((u32)pa[(dy)*RP + (dx)] | ((u32)pb[(dy)*RP + (dx)] << 16))
+                // lowest ring address of each candidate, hidden from the optimiser so that the 16 ring reads
+                // stay "this register + a non-negative immediate" (it would fold the constant back and
+                // spend an addition on every offset that comes out negative)
+                u32 pa = oa - (u32)(3 * RP + 3), pb = ob - (u32)(3 * RP + 3);
+                asm("" : "+v"(pa), "+v"(pb));
+#define RING2(dx, dy) ((u32)LDS_U8(pa + (u32)(((dy) + 3) * RP + (dx) + 3)) | ((u32)LDS_U8(pb + (u32)(((dy) + 3) * RP + (dx) + 3)) << 16))
                 // D[k] = v - ring[k] + 0x500 in each half (0x401 .. 0x5FF)
                 const u32 V = RING2(0, 0) + 0x05000500u;
                 u32 D[16];
@@ -1284,19 +1312,21 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                 int s = 0;
                 if (wi < n2) {
                     o = queue[wi];
-                    const u8* q = plane + o;
-                    const u8* qu = q - RP;
-                    const u8* qd = q + RP;
-                    const int m = q[0];
-                    const int nb = max(max(max((int)q[-1], (int)q[1]), max((int)qu[-1], (int)qu[0])),
-                                       max(max((int)qu[1], (int)qd[-1]), max((int)qd[0], (int)qd[1])));
+                    u32 q0 = (u32)g.fastPlaneOff + o - (u32)(RP + 1);  // top-left neighbour in the plane
+                    asm("" : "+v"(q0));
+#define PL(k) ((int)LDS_U8(q0 + (u32)(k)))
+                    const int m = PL(RP + 1);
+                    const int nb = max(max(max(PL(RP), PL(RP + 2)), max(PL(0), PL(1))),
+                                       max(max(PL(2), PL(2 * RP)), max(PL(2 * RP + 1), PL(2 * RP + 2))));
+#undef PL
                     keep = m > max(nb, 1);
                     s = m - 1;
                 }
                 int tot;
                 const int off = wave_excl_count(keep, &tot);
                 if (keep && total + off < cellCap) {
-                    const int yy = (int)__umulhi(o, g.fastRoiMagic), xx = (int)o - yy * RP;  // ROI row, byte in row
+                    const int yy = RPC ? (int)(o / (u32)(RPC ? RPC : 1)) : (int)__umulhi(o, g.fastRoiMagic);
+                    const int xx = (int)o - yy * RP;  // ROI row, byte in row
                     out[total + off] = ORBX_PACK(gx0 + xx - 4, gy0 + yy - 3, s);
                 }
                 total += tot;
@@ -2132,6 +2162,7 @@ struct orbx_handle {
     bool blurRows = true;                  // ORBX_BLUR_ROWS=0: per-lane form of the streaming blur (measurement knob)
     int maxPipes = 3;                      // ORBX_NPIPES: passes in flight (measurement knob)
     bool forkBlur = true;                  // ORBX_FORK_BLUR=0: the blur stays on the pass's own stream
+    bool fastGenericPitch = false;         // ORBX_FAST_GENERIC=1: the FAST kernel with the ROI pitch as a run-time value (test knob)
     int blurLds = 0;                       // ORBX_BLUR_LDS: unused LDS bytes per blur workgroup, caps its share of a compute unit (measurement knob)
     int resizeLogW = 0;                    // ORBX_RESIZE_LOGW: forces the lane split of the wave-uniform form (measurement knob)
     bool resizeRows = true;                // wave-uniform form of the streaming resize (ORBX_RESIZE_ROWS=0: per-lane form)
@@ -2402,6 +2433,7 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     if (const char* e = getenv("ORBX_BLUR_LOGW")) h->blurLogW = atoi(e);
     if (const char* e = getenv("ORBX_NPIPES")) h->maxPipes = std::min(std::max(atoi(e), 1), ORBX_PIPES);
     if (const char* e = getenv("ORBX_FORK_BLUR")) h->forkBlur = atoi(e) != 0;
+    if (const char* e = getenv("ORBX_FAST_GENERIC")) h->fastGenericPitch = atoi(e) != 0;
     if (const char* e = getenv("ORBX_BLUR_LDS")) h->blurLds = std::min(std::max(atoi(e), 0), 65536);
     if (h->qtThreads != 256 && h->qtThreads != 512 && h->qtThreads != 1024) h->qtThreads = 256;
 
@@ -2560,7 +2592,12 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
             F.w[8] = l > 0 ? (u32)(L.pyrOff + (i64)iniY * L.pyrPitch + (iniX & ~3)) : 0u;
             F.w[9] = (u32)L.pyrPitch;
             F.w[10] = magic(rw);
-            F.w[11] = 0;
+            {  // ROI rows are copied in groups of rowsW rows, the first 8 groups through registers
+                const int rowsW = 64 / nWc;
+                const int nFull = std::min(rh / rowsW, 8);
+                const int rem = nFull < 8 ? rh - nFull * rowsW : 0;
+                F.w[11] = (u32)nFull | ((u32)rem << 8);
+            }
             if (l > 0 && L.pyrOff + (i64)L.pyrPitch * L.h > 0xFFFFFFFFll) {
                 orbx_set_error("internal: pyramid block exceeds 4 GiB");
                 return ORBX_ERR_UNSUPPORTED;
@@ -2836,7 +2873,21 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         StageTimer t(h, ORBX_STAGE_FAST);
         const int aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0;
         dim3 grid(n, (g.totalCells + FAST_CPW - 1) / FAST_CPW, 1), block(64, 1, 1);
-        hipLaunchKernelGGL(k_fast, grid, block, g.fastLdsBytes, st, g, img0, aligned0, (const u8*)h->dPyr,
+        // the kernel is instantiated for every ROI pitch a cell of 30 .. 59 pixels can have
+        auto kf = k_fast<0>;
+        switch (g.fastRoiPitch) {
+            case 40: kf = k_fast<40>; break;
+            case 44: kf = k_fast<44>; break;
+            case 48: kf = k_fast<48>; break;
+            case 52: kf = k_fast<52>; break;
+            case 56: kf = k_fast<56>; break;
+            case 60: kf = k_fast<60>; break;
+            case 64: kf = k_fast<64>; break;
+            case 68: kf = k_fast<68>; break;
+            default: break;
+        }
+        if (h->fastGenericPitch) kf = k_fast<0>;
+        hipLaunchKernelGGL(kf, grid, block, g.fastLdsBytes, st, g, img0, aligned0, (const u8*)h->dPyr,
                            (const FastCell*)h->dCells, h->dCellCount, h->dSlots, std::min(std::max(h->cfg.ini_th_fast, 0), 255),
                            std::min(std::max(h->cfg.min_th_fast, 0), 255));
     }

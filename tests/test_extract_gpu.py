@@ -237,6 +237,30 @@ def test_large_batch_properties(extractor_vga):
         assert (k["angle"] >= 0).all() and (k["angle"] <= 360).all()
 
 
+@pytest.mark.parametrize("w,h,nl", [(640, 480, 8), (171, 107, 1), (151, 107, 1), (120, 107, 1), (121, 107, 1),
+                                    (82, 107, 1), (87, 107, 1), (91, 107, 1)])
+def test_fast_row_pitch_forms_equal_oracle(oracle, monkeypatch, w, h, nl):
+    """The FAST kernel is compiled once per row pitch of its cell buffer (the widest cell of the
+    pyramid, 30 .. 59 pixels, gives pitches 40 .. 68) and once with the pitch as a run-time value.
+    The shapes here have widest cells of 32, 35, 40, 44, 45, 50, 55 and 59 pixels, i.e. the pitches
+    40, 44, 48, 52, 56, 60, 64 and 68; each runs in both forms."""
+    from slam_amd.extractor import ORBextractor
+    imgs = synth.synth_batch(2, w, h, 900 + w)
+    p = oracle.params(nfeatures=600, nlevels=nl)
+    want = [oracle.extract(p, imgs[f], cap=900) for f in range(2)]
+    assert sum(len(k) for k, _ in want) > 0
+    for generic in ("0", "1"):
+        monkeypatch.setenv("ORBX_FAST_GENERIC", generic)
+        ex = ORBextractor(600, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=2)
+        try:
+            kps, desc, n = ex.extract_batch(imgs)
+            for f in range(2):
+                assert_same_features(kps[f, :n[f]], desc[f, :n[f]], want[f][0], want[f][1],
+                                     "%dx%d generic=%s frame %d" % (w, h, generic, f))
+        finally:
+            ex.close()
+
+
 def test_passes_in_flight_equal_single_frames(oracle):
     """A device-resident batch longer than one pass is spread over several passes in flight
     (own streams, own scratch slices); the result must equal frame-by-frame extraction, with
