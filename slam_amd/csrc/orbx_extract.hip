@@ -2161,7 +2161,7 @@ struct orbx_handle {
     int blurLogW = 0;                      // ORBX_BLUR_LOGW: forces the lane split of the wave-uniform blur (measurement knob)
     bool blurRows = true;                  // ORBX_BLUR_ROWS=0: per-lane form of the streaming blur (measurement knob)
     int maxPipes = 3;                      // ORBX_NPIPES: passes in flight (measurement knob)
-    bool forkBlur = true;                  // ORBX_FORK_BLUR=0: the blur stays on the pass's own stream
+    int forkBlur = 1;                      // ORBX_FORK_BLUR: 0 the blur stays on the pass's own stream, 1 forked after the pyramid, 2 forked after FAST
     bool fastGenericPitch = false;         // ORBX_FAST_GENERIC=1: the FAST kernel with the ROI pitch as a run-time value (test knob)
     int blurLds = 0;                       // ORBX_BLUR_LDS: unused LDS bytes per blur workgroup, caps its share of a compute unit (measurement knob)
     int resizeLogW = 0;                    // ORBX_RESIZE_LOGW: forces the lane split of the wave-uniform form (measurement knob)
@@ -2407,6 +2407,10 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         // strength plane has the ROI's geometry (and holds the word queue before it is cleared);
         // the pixel queue has one 16-bit entry per interior pixel
         g.fastRoiPitch = 4 * ((mw + 3) / 4 + 2);
+        if (const char* e = getenv("ORBX_FAST_PITCH")) {  // measurement knob: a wider pitch (multiple of 4) changes the LDS bank pattern
+            const int want = atoi(e) & ~3;
+            if (want > g.fastRoiPitch && want <= 128) g.fastRoiPitch = want;
+        }
         g.fastRoiMagic = div_magic((u32)g.fastRoiPitch);
         g.fastPlaneOff = align_up(g.fastRoiPitch * (mh + 6), 16);
         g.fastQueueOff = g.fastPlaneOff + align_up(g.fastRoiPitch * (mh + 6), 16);
@@ -2432,7 +2436,7 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     if (const char* e = getenv("ORBX_BLUR_ROWS")) h->blurRows = atoi(e) != 0;
     if (const char* e = getenv("ORBX_BLUR_LOGW")) h->blurLogW = atoi(e);
     if (const char* e = getenv("ORBX_NPIPES")) h->maxPipes = std::min(std::max(atoi(e), 1), ORBX_PIPES);
-    if (const char* e = getenv("ORBX_FORK_BLUR")) h->forkBlur = atoi(e) != 0;
+    if (const char* e = getenv("ORBX_FORK_BLUR")) h->forkBlur = std::min(std::max(atoi(e), 0), 2);
     if (const char* e = getenv("ORBX_FAST_GENERIC")) h->fastGenericPitch = atoi(e) != 0;
     if (const char* e = getenv("ORBX_BLUR_LDS")) h->blurLds = std::min(std::max(atoi(e), 0), 65536);
     if (h->qtThreads != 256 && h->qtThreads != 512 && h->qtThreads != 1024) h->qtThreads = 256;
@@ -2792,7 +2796,13 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         }
     }
     const bool fork = h->overlapBlur && h->forkBlur && h->auxStream != nullptr;
+    // forkBlur 1: the blur starts when the pyramid is done and runs beside FAST and the quadtree;
+    // forkBlur 2: it starts when FAST is done and runs beside the quadtree only (FAST and the blur
+    // both live on vector-instruction issue and slow each other down; the quadtree is a chain of
+    // barriers and scans that leaves most of a compute unit idle)
+    const bool lateFork = fork && h->forkBlur == 2;
     hipStream_t bst = fork ? h->auxStream : st;
+    auto launch_blur = [&]() -> int {
     if (fork) {
         ORBX_HIP_CHECK(hipEventRecord(h->evPyramid, st));
         ORBX_HIP_CHECK(hipStreamWaitEvent(h->auxStream, h->evPyramid, 0));
@@ -2869,6 +2879,12 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     if (fork) {
         ORBX_HIP_CHECK(hipEventRecord(h->evBlur, h->auxStream));
     }
+    return ORBX_OK;
+    };
+    if (!lateFork) {
+        const int rc = launch_blur();
+        if (rc != ORBX_OK) return rc;
+    }
     {
         StageTimer t(h, ORBX_STAGE_FAST);
         const int aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0;
@@ -2890,6 +2906,10 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         hipLaunchKernelGGL(kf, grid, block, g.fastLdsBytes, st, g, img0, aligned0, (const u8*)h->dPyr,
                            (const FastCell*)h->dCells, h->dCellCount, h->dSlots, std::min(std::max(h->cfg.ini_th_fast, 0), 255),
                            std::min(std::max(h->cfg.min_th_fast, 0), 255));
+    }
+    if (lateFork) {
+        const int rc = launch_blur();
+        if (rc != ORBX_OK) return rc;
     }
     {
         StageTimer t(h, ORBX_STAGE_QUADTREE);
