@@ -47,8 +47,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--chunk", type=int, default=512, help="frames per internal pass")
     ap.add_argument("--cpu-frames", type=int, default=1024, help="sample size of the CPU baseline")
-    ap.add_argument("--schedule", choices=["both", "default"], default="both",
-                    help="default: only the timed region (the library's default schedule); both: also a serialised run")
+    ap.add_argument("--schedule", choices=["both", "default", "serial"], default="both",
+                    help="default: only the timed region (the library's default schedule); both: also a serialised run; "
+                         "serial: the timed region itself runs one pass at a time on one stream (for a kernel "
+                         "trace in which every duration is the kernel's own)")
     ap.add_argument("--roofline-kernel", default="auto", choices=["auto", "pyramid", "fast", "quadtree", "blur", "describe"],
                     help="stage reported in `roofline` (auto: largest share of the serialised time)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -143,7 +145,7 @@ def main():
     # flight on their own streams, the blur of a pass beside its FAST + quadtree.  Stage times
     # are HIP events around each stage on the stream it runs on, so under this schedule they
     # include the time a kernel shares the GPU with the other passes.
-    elapsed, prof = timed(True)
+    elapsed, prof = timed(args.schedule != "serial")
     total_frames = world * B * args.steps
     value = total_frames / elapsed
     stages = stage_table(prof)
@@ -217,7 +219,8 @@ def main():
                                "(1000 features, 8 levels, scale 1.2, FAST 20/7), frames and outputs "
                                "resident in HBM" % B,
                    "frames_per_gpu": B, "frames_per_pass": ex.max_batch,
-                   "schedule": "up to 3 passes in flight, blur beside FAST + quadtree",
+                   "schedule": ("one pass at a time on one stream (--schedule serial)" if args.schedule == "serial"
+                                else "up to 3 passes in flight, blur beside FAST + quadtree"),
                    "parallelism": "frames sharded, no collective"},
         "roofline": roofline, "stages": stages,
     }

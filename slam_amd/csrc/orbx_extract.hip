@@ -1918,13 +1918,14 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
     if (sBase >= total) return;
 
     // tables: this lane's 4 disc words and its 4 tests (one per round), kept in registers
-    u32 wU[4], wM[4];
+    u32 wU[4], wM[4], wV[4];
     float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int slot = min(lane + 64 * i, 247);
         wU[i] = lane + 64 * i < 248 ? d_tables.patchU[slot] : 0u;
         wM[i] = lane + 64 * i < 248 ? d_tables.patchM[slot] : 0u;
+        wV[i] = wM[i] * (u32)(slot >> 3);  // membership bytes (0 / 1) times the word's row (v + 15): no carries
         const int pw = (int)d_tables.pattern[i * 64 + lane];
         px0[i] = (float)((pw << 24) >> 24);
         py0[i] = (float)((pw << 16) >> 24);
@@ -2002,19 +2003,22 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
         __builtin_amdgcn_sched_barrier(0);
         issue_windows(0);
         __builtin_amdgcn_sched_barrier(0);
+        // Per lane: D = sum px * (u + 15), E = sum px * (v + 15), S = sum px over the disc bytes of its four
+        // words, each a chain of four dot products (the accumulator input does the additions); then
+        // m10 = D - 15 S and m01 = E - 15 S.  All three sums stay below 2^17, so the product is a
+        // 24-bit multiply.
 #pragma unroll
         for (int j = 0; j < DESC_KPW; j++) {
-            int m10 = 0, m01 = 0;
+            u32 D = 0, E = 0, S = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int v = (min(lane + 64 * i, 247) >> 3) - 15;
-                const int D = (int)__builtin_amdgcn_udot4(px[j][i], wU[i], 0u, false);
-                const int S = (int)__builtin_amdgcn_udot4(px[j][i], wM[i], 0u, false);
-                m10 += D - 15 * S;
-                m01 += v * S;
+                D = __builtin_amdgcn_udot4(px[j][i], wU[i], D, false);
+                E = __builtin_amdgcn_udot4(px[j][i], wV[i], E, false);
+                S = __builtin_amdgcn_udot4(px[j][i], wM[i], S, false);
             }
-            V[2 * j] = m10;
-            V[2 * j + 1] = m01;
+            const int S15 = (int)mul24(S, 15u);
+            V[2 * j] = (int)D - S15;
+            V[2 * j + 1] = (int)E - S15;
         }
     }
     // B: halving exchange.  After the steps with lane distance 32, 16, 8, 4 a lane holds the

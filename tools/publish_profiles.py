@@ -12,6 +12,12 @@ src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "kernel_stats_%s.csv" % tag), os.path.join("profiles", "%s_kernel_stats.csv" % tag))
 shutil.copy(os.path.join(src, "summary_%s.json" % tag), os.path.join("profiles", "%s_summary.json" % tag))
+ser = os.path.join(src, "kernel_stats_serialized_%s.csv" % tag)
+if os.path.exists(ser):
+    shutil.copy(ser, os.path.join("profiles", "%s_kernel_stats_serialized.csv" % tag))
+fullser = os.path.join(src, "serial", "s_kernel_stats.csv")
+if os.path.exists(fullser):
+    shutil.copy(fullser, os.path.join("profiles", "%s_rocprofv3_kernel_stats_serialized_full.csv" % tag))
 full = os.path.join(src, "stats", "s_kernel_stats.csv")
 if os.path.exists(full):
     shutil.copy(full, os.path.join("profiles", "%s_rocprofv3_kernel_stats_full.csv" % tag))

@@ -26,9 +26,12 @@ def mine(name):
     return "k_" in name and "at::native" not in name
 
 
-stats = collections.OrderedDict()
-p = os.path.join(src, "stats", "s_kernel_trace.csv")
-if os.path.exists(p):
+def kernel_table(sub, out_name):
+    """Per-kernel durations of one rocprofv3 kernel trace -> a small csv; returns {kernel: stats}."""
+    res = collections.OrderedDict()
+    p = os.path.join(src, sub, "s_kernel_trace.csv")
+    if not os.path.exists(p):
+        return res
     per = collections.defaultdict(list)
     meta = {}
     for r in csv.DictReader(open(p)):
@@ -37,11 +40,16 @@ if os.path.exists(p):
         k = short(r["Kernel_Name"])
         per[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size_X"])
-    with open(os.path.join(dst, "kernel_stats_%s.csv" % tag), "w") as f:
+    with open(os.path.join(dst, out_name), "w") as f:
         f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,vgpr,sgpr,lds_bytes,workgroup\n")
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
             f.write("%s,%d,%d,%.1f,%d,%d,%s,%s,%s,%s\n" % ((k, len(v), sum(v), sum(v) / len(v), min(v), max(v)) + meta[k]))
-            stats[k] = {"calls": len(v), "avg_ns": sum(v) / len(v)}
+            res[k] = {"calls": len(v), "avg_ns": sum(v) / len(v)}
+    return res
+
+
+stats = kernel_table("stats", "kernel_stats_%s.csv" % tag)                 # the library's default (concurrent) schedule
+stats_serial = kernel_table("serial", "kernel_stats_serialized_%s.csv" % tag)  # one pass at a time on one stream
 
 traffic = {}
 for kind, sub, pre in (("FETCH_SIZE", "fetch", "f"), ("WRITE_SIZE", "write", "w")):
@@ -64,5 +72,5 @@ for k, t in traffic.items():
     t["read_bytes_corrected"] = rd
     t["write_bytes"] = wr
     t["frames_per_launch"] = 512
-json.dump({"tag": tag, "kernels": stats, "traffic": traffic}, open(os.path.join(dst, "summary_%s.json" % tag), "w"), indent=1)
+json.dump({"tag": tag, "kernels": stats, "kernels_serialized": stats_serial, "traffic": traffic}, open(os.path.join(dst, "summary_%s.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
