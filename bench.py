@@ -198,6 +198,7 @@ def main():
                 "avg_launch_ms": stages[dominant]["ms_per_launch"],
                 "avg_launch_ms_serialized": st2[dominant]["ms_per_launch"],
                 "achieved_serialized": st2[dominant].get("achieved_GBs"),
+                "frac_serialized": round((st2[dominant].get("achieved_GBs") or 0.0) / HBM_PEAK_GBS, 5),
                 "time_share": round(st2[dominant]["ms_total"] / sum(s["ms_total"] for s in st2.values()), 3),
                 "kernel_source_hash": src_hash}
     if traffic_note:
