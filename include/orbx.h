@@ -124,7 +124,9 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int h_
 /* mvImagePyramid[level] of frame `frame` of the last extract call (public
  * member read by Frame::ComputeStereoMatches, reference src/Frame.cc:610,700).
  * *ptr is DEVICE memory owned by the handle (level 0 aliases the caller's
- * image when it was passed as device memory), valid until the next call.  A batch longer
+ * image when it was passed as device memory with base, row stride and image stride multiples
+ * of 4; any other device layout is copied once to aligned rows on the device and level 0 is
+ * that copy), valid until the next call.  A batch longer
  * than max_batch is processed in passes; only the frames of the last pass stay resident. */
 int orbx_get_level(orbx_handle* h, int frame, int level, const uint8_t** ptr, int* w, int* h_,
                    size_t* stride);

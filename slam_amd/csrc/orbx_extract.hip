@@ -902,6 +902,26 @@ __global__ __launch_bounds__(256) void k_blur_rows(Geom g, ImgRef img0, const u8
     }
 }
 
+// ------------------------------------------------------------------ level-0 repack
+// Rows of a device-resident image whose base, row stride or frame stride is not a multiple of 4 (a
+// 1241-pixel-wide image with contiguous rows, say) are copied once to rows of a 64-byte-aligned pitch,
+// so that every kernel of the pass takes its word-aligned path.  A thread moves one 32-bit word: an
+// unaligned load from the source row, an aligned store; the last word of a row is assembled from
+// bytes so that nothing beyond the row is read.
+__global__ __launch_bounds__(256) void k_repack_rows(ImgRef src, int w, u8* __restrict__ dst, int dPitch, i64 dFrame) {
+    const int xw = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, f = blockIdx.z;
+    if (4 * xw >= w) return;
+    const u8* sp = src.base + (i64)f * src.frameStride + (i64)y * src.pitch + 4 * xw;
+    u32 v;
+    if (4 * xw + 4 <= w) {
+        __builtin_memcpy(&v, sp, 4);
+    } else {
+        v = 0;
+        for (int k = 0; 4 * xw + k < w; k++) v |= (u32)sp[k] << (8 * k);
+    }
+    *(u32*)(dst + (i64)f * dFrame + (i64)y * dPitch + 4 * xw) = v;
+}
+
 // ------------------------------------------------------------------ FAST
 __device__ __forceinline__ int wave_excl_count(bool flag, int* total) {
     const u64 m = __ballot(flag);
@@ -2166,6 +2186,7 @@ struct orbx_handle {
     bool blurRows = true;                  // ORBX_BLUR_ROWS=0: per-lane form of the streaming blur (measurement knob)
     int maxPipes = 3;                      // ORBX_NPIPES: passes in flight (measurement knob)
     int forkBlur = 1;                      // ORBX_FORK_BLUR: 0 the blur stays on the pass's own stream, 1 forked after the pyramid, 2 forked after FAST
+    bool noRepack = false;                 // ORBX_NO_REPACK=1: device-resident frames with an unaligned layout are read in place (test knob)
     bool fastGenericPitch = false;         // ORBX_FAST_GENERIC=1: the FAST kernel with the ROI pitch as a run-time value (test knob)
     int blurLds = 0;                       // ORBX_BLUR_LDS: unused LDS bytes per blur workgroup, caps its share of a compute unit (measurement knob)
     int resizeLogW = 0;                    // ORBX_RESIZE_LOGW: forces the lane split of the wave-uniform form (measurement knob)
@@ -2201,6 +2222,8 @@ struct orbx_handle {
     size_t imgStageCap = 0;
     u8* dRawStage = nullptr;  // host rows as they are (any row stride), before the repack to the staged pitch
     size_t rawStageCap = 0;
+    u8* dAlignStage = nullptr;  // aligned copies of device-resident frames whose layout is not word-aligned (one slice per pass in flight)
+    size_t alignStageCap = 0;
     orbx_keypoint* dKpStage = nullptr;
     u8* dDescStage = nullptr;
     int* dNStage = nullptr;
@@ -2441,6 +2464,7 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     if (const char* e = getenv("ORBX_BLUR_LOGW")) h->blurLogW = atoi(e);
     if (const char* e = getenv("ORBX_NPIPES")) h->maxPipes = std::min(std::max(atoi(e), 1), ORBX_PIPES);
     if (const char* e = getenv("ORBX_FORK_BLUR")) h->forkBlur = std::min(std::max(atoi(e), 0), 2);
+    if (const char* e = getenv("ORBX_NO_REPACK")) h->noRepack = atoi(e) != 0;
     if (const char* e = getenv("ORBX_FAST_GENERIC")) h->fastGenericPitch = atoi(e) != 0;
     if (const char* e = getenv("ORBX_BLUR_LDS")) h->blurLds = std::min(std::max(atoi(e), 0), 65536);
     if (h->qtThreads != 256 && h->qtThreads != 512 && h->qtThreads != 1024) h->qtThreads = 256;
@@ -3036,7 +3060,7 @@ void orbx_destroy(orbx_handle* h) {
     }
     if (h->evStart) (void)hipEventDestroy(h->evStart);
     if (h->hErr) (void)hipHostFree(h->hErr);
-    free_dev(h->dTaps); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dRawStage); free_dev(h->dKpStage);
+    free_dev(h->dTaps); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dRawStage); free_dev(h->dAlignStage); free_dev(h->dKpStage);
     free_dev(h->dDescStage); free_dev(h->dNStage);
     for (int s = 0; s < ORBX_STAGE_COUNT; s++)
         for (auto& e : h->prof.ev[s]) {
@@ -3154,6 +3178,22 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
             h->outStageCap = outN;
         }
     }
+    // Device-resident frames whose layout is not word-aligned are repacked pass by pass (ORBX_NO_REPACK=1
+    // keeps the unaligned forms of the kernels, which the tests compare with the repacked path).
+    const bool repackDevice = mem_space == ORBX_MEM_DEVICE && !h->noRepack && hh <= 65535 && chunk <= 65535 &&
+                              (((((uintptr_t)imgs) | (uintptr_t)row_stride | (uintptr_t)img_stride) & 3u) != 0 ||
+                               row_stride < (size_t)align_up(w, 4));
+    if (repackDevice) {
+        const size_t need = (size_t)chunk * npipes * align_up(w, 64) * hh;
+        if (need > h->alignStageCap) {
+            ORBX_HIP_CHECK(hipDeviceSynchronize());
+            free_dev(h->dAlignStage);
+            h->dAlignStage = nullptr;
+            h->alignStageCap = 0;
+            ORBX_HIP_CHECK(hipMalloc((void**)&h->dAlignStage, need + 256));
+            h->alignStageCap = need;
+        }
+    }
     for (int f0 = 0; f0 < B; f0 += chunk) {
         const int n = std::min(chunk, B - f0);
         ImgRef img0;
@@ -3216,6 +3256,17 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
                 h->evBlur = h->pipes[p].evBlur;
             }
             select_scratch(h, (size_t)p * chunk);
+            if (repackDevice) {
+                // one read and one write of the frame buys the word-aligned forms of the resize, the
+                // FAST cell copy and the blur for level 0 (1241 x 376: 146 k -> 2xx k frames/s)
+                const int sp = align_up(w, 64);
+                u8* slice = h->dAlignStage + (size_t)p * chunk * sp * hh;
+                dim3 grid((((w + 3) / 4) + 255) / 256, hh, n), block(256, 1, 1);
+                hipLaunchKernelGGL(k_repack_rows, grid, block, 0, h->stream, img0, w, slice, sp, (i64)sp * hh);
+                img0.base = slice;
+                img0.pitch = sp;
+                img0.frameStride = (i64)sp * hh;
+            }
             rc = run_pass(h, img0, n, kps + (size_t)f0 * cap, desc + (size_t)f0 * cap * 32, cap, n_out + f0);
             h->stream = mainStream;
             h->auxStream = mainAux;

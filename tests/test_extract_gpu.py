@@ -299,20 +299,26 @@ def test_passes_in_flight_equal_single_frames(oracle):
         one.close()
 
 
-def test_width_not_multiple_of_four_device_resident(oracle):
+@pytest.mark.parametrize("no_repack", ["0", "1"])
+def test_width_not_multiple_of_four_device_resident(oracle, monkeypatch, no_repack):
     """KITTI-sized frames (1241 px wide) in device memory with rows padded to 1244 bytes take the
-    aligned word paths; with a tight pitch of 1241 they take the byte paths.  Same result."""
+    aligned word paths.  With a tight pitch of 1241, or a base address that is not a multiple of 4,
+    the frames are first copied to aligned rows on the device (no_repack 0), or read in place by the
+    byte forms of the kernels (no_repack 1).  Same result; several passes in flight, each with its own
+    slice of the aligned copies."""
     import torch
     from slam_amd._lib import KP_DTYPE
     from slam_amd.extractor import ORBextractor
-    w, h, B = 1241, 376, 3
+    monkeypatch.setenv("ORBX_NO_REPACK", no_repack)
+    w, h, B = 1241, 376, 5
     host = synth.synth_batch(B, w, h, 900)
-    ex = ORBextractor(2000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+    ex = ORBextractor(2000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
     try:
         cap = ex.max_keypoints()
         want = [oracle.extract(oracle.params(nfeatures=2000), host[f], cap=cap) for f in range(B)]
-        for pitch in (1244, 1241, 1280):
-            buf = torch.zeros((B, h, pitch), dtype=torch.uint8, device="cuda")
+        for pitch, shift in ((1244, 0), (1241, 0), (1280, 0), (1244, 1), (1241, 3)):
+            flat = torch.zeros(B * h * pitch + 8, dtype=torch.uint8, device="cuda")
+            buf = flat[shift:shift + B * h * pitch].view(B, h, pitch)
             buf[:, :, :w] = torch.from_numpy(host).cuda()
             d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
             d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Frames/s of the VGA benchmark shape under the library's concurrent schedule:
-    python3 tools/probe/pipes.py [library] [frames] [frames per pass]
+    python3 tools/probe/pipes.py [library] [frames] [frames per pass] [width height features]
 Run with ORBX_NPIPES / GPU_MAX_HW_QUEUES in the environment to sweep the passes in flight and
 the hardware queues they map to."""
 import os
@@ -19,14 +19,17 @@ from slam_amd.extractor import ORBextractor  # noqa: E402
 
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 512
-ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=chunk)
+W, H, NF = (int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (640, 480, 1000)
+ex = ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=chunk)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 ex.set_stream(st.cuda_stream)
 cap = ex.max_keypoints()
-fr = torch.empty((B, 480, 640), dtype=torch.uint8, device="cuda")
-for f0 in range(0, B, 128):
-    fr[f0:f0 + 128] = synth.synth_batch_torch(128, 640, 480, 0x5EED0001 + f0, device="cuda")
+fr = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
+step = 128 if W * H <= 640 * 480 else 8
+for f0 in range(0, B, step):
+    nb = min(step, B - f0)
+    fr[f0:f0 + nb] = synth.synth_batch_torch(nb, W, H, 0x5EED0001 + f0, device="cuda")
 k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
 d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
 n = torch.zeros(B, dtype=torch.int32, device="cuda")
@@ -41,6 +44,6 @@ for _ in range(steps):
 ex.synchronize()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("lib=%s frames=%d chunk=%d npipes=%s hwq=%s: %.0f frames/s" % (
-    os.path.basename(_lib.LIB_PATH), B, chunk, os.environ.get("ORBX_NPIPES", "-"),
+print("lib=%s %dx%d/%d frames=%d chunk=%d npipes=%s hwq=%s: %.0f frames/s" % (
+    os.path.basename(_lib.LIB_PATH), W, H, NF, B, chunk, os.environ.get("ORBX_NPIPES", "-"),
     os.environ.get("GPU_MAX_HW_QUEUES", "-"), steps * B / dt), flush=True)
