@@ -428,7 +428,7 @@ def main():
         frames = d_kps = d_desc = d_n = None
         torch.cuda.empty_cache()
         for name, (w2, h2, nf2, b2, ch2) in {"kitti_1241x376_2000kp": (1241, 376, 2000, 1024, 256),
-                                              "uhd_3840x2160_10000kp": (3840, 2160, 10000, 64, 16)}.items():
+                                              "uhd_3840x2160_10000kp": (3840, 2160, 10000, 128, 32)}.items():
             try:
                 e2 = ORBextractor(nf2, 1.2, NLEVELS, 20, 7, max_width=w2, max_height=h2, max_batch=ch2, device=local_rank)
                 e2.set_stream(stream.cuda_stream)

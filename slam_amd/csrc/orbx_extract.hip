@@ -2757,9 +2757,11 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     const Geom& g = h->g;
     hipStream_t st = h->stream;
     // the one-launch pyramid wants a workgroup per frame on most compute units; small batches go level by level
+    // (640x480, serialised, us per frame, one launch against seven: 128 frames 0.88 / 0.75, 192 frames 0.63 / 0.69,
+    // 256 frames 0.48 / 0.66)
     const i64 imgBytes0 = (i64)(g.h - 1) * img0.pitch + g.w;
     const bool fusedPyramid = h->pyrFrameOk && h->resizeRows && imgBytes0 <= 0x7FFFFFFFll &&
-                              (h->pyrFused >= 0 ? h->pyrFused != 0 : n >= 128);
+                              (h->pyrFused >= 0 ? h->pyrFused != 0 : n >= 160);
     if (fusedPyramid) {
         StageTimer t(h, ORBX_STAGE_PYRAMID);
         PyramidArgs args = h->pyrArgs;

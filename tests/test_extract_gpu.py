@@ -206,6 +206,28 @@ def test_4k_10k_features(oracle):
         ex.close()
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (1241, 376, 2000), (322, 243, 400)])
+def test_pyramid_forms_equal_oracle(oracle, monkeypatch, fused, w, h, nf):
+    """The pyramid is built either level by level (small batches) or by one launch in which a
+    workgroup runs all levels of a frame (batches that give most compute units a frame); here both
+    forms are forced on a small batch and compared with the oracle level by level and end to end."""
+    from slam_amd.extractor import ORBextractor
+    monkeypatch.setenv("ORBX_PYR_FUSED", fused)
+    imgs = synth.synth_batch(3, w, h, 4100 + w)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=3)
+    try:
+        kps, desc, n = ex.extract_batch(imgs)
+        p = oracle.params(nfeatures=nf)
+        for f in range(3):
+            for lvl in range(1, 8):
+                assert np.array_equal(ex.image_pyramid_level(f, lvl), oracle.pyramid_level(p, imgs[f], lvl)), (f, lvl)
+            rk, rd = oracle.extract(p, imgs[f], cap=nf + 128)
+            assert_same_features(kps[f, :n[f]], desc[f, :n[f]], rk, rd, "%dx%d fused=%s frame %d" % (w, h, fused, f))
+    finally:
+        ex.close()
+
+
 def test_large_batch_properties(extractor_vga):
     """At a batch size the oracle is too slow for: size-independent properties.  Identical
     frames give identical outputs wherever they sit in the batch, and every output obeys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Serialised per-stage times of the VGA benchmark shape with another build of the library:
-    python3 tools/probe/lib_variant.py tools/probe/bin/liborbx_xyz.so
+    python3 tools/probe/lib_variant.py tools/probe/bin/liborbx_xyz.so [frames per pass]
 (for compile-time constants that have no run-time knob)."""
 import os
 import sys
@@ -10,13 +10,14 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from slam_amd import _lib  # noqa: E402
 
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] != "-":
     _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+MB = int(sys.argv[2]) if len(sys.argv) > 2 else 512   # frames per pass
 from slam_amd import synth  # noqa: E402
 from slam_amd.extractor import ORBextractor  # noqa: E402
 
 B = 2048
-ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=512)
+ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=MB)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 ex.set_stream(st.cuda_stream)
@@ -37,4 +38,4 @@ for _ in range(3):
     ex.extract_batch_device(fr, k, d, n, cap)
 ex.synchronize()
 prof = ex.profile_read()
-print(os.path.basename(_lib.LIB_PATH), {name: round(1000.0 * ms / (3 * B), 4) for name, (ms, _) in prof.items()})
+print(os.path.basename(_lib.LIB_PATH), "frames per pass", MB, {name: round(1000.0 * ms / (3 * B), 4) for name, (ms, _) in prof.items()})
