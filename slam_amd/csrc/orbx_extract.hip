@@ -994,9 +994,9 @@ __device__ unsigned long long* d_fastDiag;
 #define FAST_STAMP(i)
 #endif
 
-// The dynamic LDS array is the only LDS object of k_fast, so it starts at LDS address 0 and a byte
-// offset into it is an LDS address: reads through these forms take "register + immediate" with no
-// addition of the array's (zero) base.
+// LDS accesses of k_fast by LDS address (the address of its dynamic array + a byte offset): written
+// this way a read is "base register + immediate offset", and the array's address joins the other
+// constants of the base register instead of costing an addition per access.
 #define LDS_U8(a) (*(const __attribute__((address_space(3))) u8*)(size_t)(u32)(a))
 #define LDS_U32(a) (*(const __attribute__((address_space(3))) u32*)(size_t)(u32)(a))
 #define LDS_U32W(a) (*(__attribute__((address_space(3))) u32*)(size_t)(u32)(a))
@@ -1030,8 +1030,9 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                                               const FastCell* __restrict__ cells, u32* __restrict__ cellCount,
                                               u32* __restrict__ slots, int iniTh, int minTh) {
     extern __shared__ __align__(16) u8 lds[];
-    // LDS_U8 / LDS_U32 take offsets into this array as LDS addresses (resolved at compile time)
-    if ((u32)(size_t)(const __attribute__((address_space(3))) u8*)lds != 0u) __builtin_trap();
+    // LDS_U8 / LDS_U32 take LDS addresses: the array's own address (a link-time constant, 0 while it is
+    // the kernel's only LDS object) is folded into every base register below, at no cost
+    const u32 L0 = (u32)(size_t)(const __attribute__((address_space(3))) u8*)lds;
     u8* roi = lds;
     u8* plane = lds + g.fastPlaneOff;
     u32* wq = (u32*)plane;  // the word queue is dead before the plane is cleared
@@ -1097,7 +1098,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
         const int nWc = (int)(C.w[7] & 255), rowsW = (int)((C.w[7] >> 8) & 255);
         const int lw = (int)fastdiv((u32)lane, (u32)nWc, C.w[5]), wd = lane - lw * nWc;
         if (lw < rowsW) {
-            u32 doff = mul24((u32)lw, (u32)RP) + 4u * (u32)wd;
+            u32 doff = L0 + mul24((u32)lw, (u32)RP) + 4u * (u32)wd;
             const u32 dStep = (u32)(rowsW * RP);
             const int nFull = (int)(C.w[11] & 255u), rem = (int)((C.w[11] >> 8) & 255u);
 #pragma unroll
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                 const u32 sStep = (u32)(rowsW * pitch);
                 for (int y = lw + 8 * rowsW; y < rh; y += rowsW) {
                     const FastPair w = *(const FastPair*)(sbase + soff);
-                    *(u32*)(roi + doff) = __builtin_amdgcn_alignbyte(w.b, w.a, sh);
+                    LDS_U32W(doff) = __builtin_amdgcn_alignbyte(w.b, w.a, sh);
                     soff += sStep;
                     doff += dStep;
                 }
@@ -1185,7 +1186,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
             const u32 K1 = k1 | (k1 << 16), K2 = k2 | (k2 << 16);
             int nW = 0;
             {
-                u32 r0 = entBase - (u32)(3 * RP + 4);
+                u32 r0 = entBase + (L0 - (u32)(3 * RP + 4));
                 u32 ent = entBase;
                 for (int yb = 0; yb < ih; yb += rowsPer) {
                     u32 m = 0;
@@ -1252,7 +1253,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                 // lowest ring address of each candidate, hidden from the optimiser so that the 16 ring reads
                 // stay "this register + a non-negative immediate" (it would fold the constant back and
                 // spend an addition on every offset that comes out negative)
-                u32 pa = oa - (u32)(3 * RP + 3), pb = ob - (u32)(3 * RP + 3);
+                u32 pa = oa + (L0 - (u32)(3 * RP + 3)), pb = ob + (L0 - (u32)(3 * RP + 3));
                 asm("" : "+v"(pa), "+v"(pb));
 #define RING2(dx, dy) ((u32)LDS_U8(pa + (u32)(((dy) + 3) * RP + (dx) + 3)) | ((u32)LDS_U8(pb + (u32)(((dy) + 3) * RP + (dx) + 3)) << 16))
                 // D[k] = v - ring[k] + 0x500 in each half (0x401 .. 0x5FF)
@@ -1332,7 +1333,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                 int s = 0;
                 if (wi < n2) {
                     o = queue[wi];
-                    u32 q0 = (u32)g.fastPlaneOff + o - (u32)(RP + 1);  // top-left neighbour in the plane
+                    u32 q0 = o + (L0 + (u32)g.fastPlaneOff - (u32)(RP + 1));  // top-left neighbour in the plane
                     asm("" : "+v"(q0));
 #define PL(k) ((int)LDS_U8(q0 + (u32)(k)))
                     const int m = PL(RP + 1);
