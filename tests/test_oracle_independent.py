@@ -1,0 +1,273 @@
+"""Whole-image cross-checks of the oracle's image primitives against statements of the same
+arithmetic that share no code with it: scipy's integer correlation for the 7x7 blur, a vectorised
+numpy statement of the fixed-point bilinear resize, torch's float bilinear interpolation (within one
+grey level), and numpy statements of the orientation moments and the descriptor tests.
+
+These pin the oracle to the published algorithms; they do not pin it to an OpenCV binary (none is
+available, and the reference holds no fixtures for this path)."""
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import pyoracle
+    return pyoracle
+
+
+IMAGES = [(640, 480, 11), (533, 400, 12), (179, 134, 13), (61, 47, 14), (9, 8, 15)]
+
+
+@pytest.mark.parametrize("w,h,seed", IMAGES)
+@pytest.mark.parametrize("variant,kernel", [(0, [18, 34, 49, 55, 49, 34, 18]), (1, [18, 34, 48, 56, 48, 34, 18])])
+def test_blur_equals_integer_correlation(oracle, w, h, seed, variant, kernel):
+    """(sum_y k_y sum_x k_x p + 32768) >> 16 with reflect-101 borders: scipy's `mirror` mode."""
+    from scipy.ndimage import correlate1d
+    img = synth.synth_image(w, h, seed)
+    k = np.array(kernel, np.int64)
+    rows = correlate1d(img.astype(np.int64), k, axis=1, mode="mirror")
+    full = correlate1d(rows, k, axis=0, mode="mirror")
+    expect = np.minimum((full + 32768) >> 16, 255).astype(np.uint8)
+    assert np.array_equal(oracle.gaussian7(img, variant), expect)
+
+
+@pytest.mark.parametrize("w,h,seed", IMAGES[:4])
+def test_blur_float_column_variant(oracle, w, h, seed):
+    """Variant 2: the same integer sums, divided by 2^16 and rounded to nearest even (the last w % 4
+    columns half up): differs from variant 0 only where the sum sits exactly on a half."""
+    from scipy.ndimage import correlate1d
+    img = synth.synth_image(w, h, seed)
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    full = correlate1d(correlate1d(img.astype(np.int64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    q, r = full >> 16, full & 0xFFFF
+    even = q + ((r > 0x8000) | ((r == 0x8000) & ((q & 1) == 1)))
+    half_up = (full + 32768) >> 16
+    expect = even.copy()
+    tail = w - (w % 4)
+    expect[:, tail:] = half_up[:, tail:]
+    assert np.array_equal(oracle.gaussian7(img, 2), np.minimum(expect, 255).astype(np.uint8))
+
+
+def _resize_numpy(src, dw, dh):
+    """cv::resize, 8-bit INTER_LINEAR, generic fixed-point path, written with whole-array operations:
+    source position fx = (dx + 0.5) * scale - 0.5 in single precision, 11-bit weights rounded to
+    nearest even, columns clamped with the weight moved to the kept tap, rows clamped by index only,
+    vertical combine ((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2 >> 2."""
+    sh, sw = src.shape
+
+    def taps(dn, sn, zero_weight_at_edges):
+        scale = 1.0 / (float(dn) / float(sn))
+        d = np.arange(dn, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        if zero_weight_at_edges:
+            lo, hi = s < 0, s >= sn - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            s = np.where(lo, 0, np.where(hi, sn - 1, s))
+        w1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        return s, w0, w1
+
+    sx, a0, a1 = taps(dw, sw, True)
+    sy, b0, b1 = taps(dh, sh, False)
+    s = src.astype(np.int64)
+    x1 = np.minimum(sx + 1, sw - 1)
+    t = s[:, sx] * a0[None, :] + s[:, x1] * a1[None, :]          # (sh, dw) horizontal sums
+    y0 = np.clip(sy, 0, sh - 1)
+    y1 = np.clip(sy + 1, 0, sh - 1)
+    top = (b0[:, None] * (t[y0] >> 4)) >> 16
+    bot = (b1[:, None] * (t[y1] >> 4)) >> 16
+    return ((top + bot + 2) >> 2).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h,dw,dh,seed", [(640, 480, 533, 400, 21), (533, 400, 444, 333, 22), (214, 161, 179, 134, 23),
+                                            (1241, 376, 1034, 313, 24), (100, 80, 50, 40, 25), (97, 61, 81, 51, 26),
+                                            (64, 48, 64, 48, 27), (640, 480, 320, 200, 28)])
+def test_resize_equals_vectorised_statement(oracle, w, h, dw, dh, seed):
+    img = synth.synth_image(w, h, seed)
+    assert np.array_equal(oracle.resize_linear(img, dw, dh), _resize_numpy(img, dw, dh))
+
+
+@pytest.mark.parametrize("w,h,dw,dh,seed", [(640, 480, 533, 400, 31), (309, 231, 257, 193, 32)])
+def test_resize_within_one_level_of_float_bilinear(oracle, w, h, dw, dh, seed):
+    """Half-pixel-centre bilinear interpolation in float (torch, align_corners=False) is the
+    real-valued function the fixed-point path approximates."""
+    import torch
+    img = synth.synth_image(w, h, seed)
+    t = torch.from_numpy(img.astype(np.float32))[None, None]
+    ref = torch.nn.functional.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False)[0, 0].numpy()
+    got = oracle.resize_linear(img, dw, dh).astype(np.float32)
+    assert np.abs(got - ref).max() <= 1.0 + 1e-3
+
+
+def test_pyramid_levels_are_successive_resizes(oracle):
+    """ComputePyramid (reference src/ORBextractor.cc:1117-1145): level l is the resize of level l - 1
+    to cvRound(size / scale_l), not of level 0."""
+    p = oracle.params()
+    img = synth.synth_image(640, 480, 41)
+    sizes = [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193), (214, 161), (179, 134)]
+    prev = img
+    for lvl in range(1, 8):
+        w, h = sizes[lvl]
+        cur = _resize_numpy(prev, w, h)
+        assert np.array_equal(oracle.pyramid_level(p, img, lvl), cur), lvl
+        prev = cur
+
+
+def _tables():
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_tables.npz"))
+    return d["bit_pattern_31"].reshape(256, 4), d["umax"]
+
+
+def test_orientation_moments_from_the_reference_tables(oracle):
+    """IC_Angle (reference src/ORBextractor.cc:59-88): m10 = sum u I, m01 = sum v I over the disc
+    rows |u| <= umax[|v|]; the angle is fastAtan2(m01, m10), checked here against atan2 in double
+    precision (the polynomial's published error bound is 0.3 degrees)."""
+    _, umax = _tables()
+    img = synth.synth_image(200, 160, 51)
+    rng = np.random.default_rng(5)
+    I = img.astype(np.int64)
+    for _ in range(200):
+        x, y = int(rng.integers(20, 180)), int(rng.integers(20, 140))
+        m10 = m01 = 0
+        for v in range(-15, 16):
+            d = int(umax[abs(v)])
+            row = I[y + v, x - d:x + d + 1]
+            m10 += int((np.arange(-d, d + 1) * row).sum())
+            m01 += v * int(row.sum())
+        want = np.degrees(np.arctan2(m01, m10)) % 360.0
+        got = oracle.ic_angle(img, x, y)
+        assert abs((got - want + 180.0) % 360.0 - 180.0) < 0.31, (x, y, got, want)
+        assert got == oracle.fast_atan2(np.float32(m01), np.float32(m10))
+
+
+def test_descriptor_from_the_reference_pattern(oracle):
+    """computeOrbDescriptor (reference src/ORBextractor.cc:92-131) with the pattern read from the
+    reference's source text: bit i of the descriptor = I(p0_i) < I(p1_i), each point steered by
+    the keypoint angle, coordinates rounded to nearest even, in single precision and in the order
+    written (x*b + y*a, x*a - y*b; no fused multiply-add)."""
+    pat, _ = _tables()
+    img = oracle.gaussian7(synth.synth_image(160, 120, 61))
+    rng = np.random.default_rng(6)
+    f32 = np.float32
+    for _ in range(60):
+        x, y = int(rng.integers(20, 140)), int(rng.integers(20, 100))
+        deg = f32(rng.uniform(0, 360))
+        rad = f32(deg * f32(np.pi / 180.0))
+        sn, cs = oracle.sincosf(np.array([rad], np.float32))
+        a, b = f32(cs[0]), f32(sn[0])
+
+        def at(px, py):
+            px, py = f32(px), f32(py)
+            r = int(np.rint(f32(f32(px * b) + f32(py * a))))
+            c = int(np.rint(f32(f32(px * a) - f32(py * b))))
+            return int(img[y + r, x + c])
+
+        bits = [at(p[0], p[1]) < at(p[2], p[3]) for p in pat]
+        want = np.packbits(np.array(bits, np.uint8), bitorder="little")
+        assert np.array_equal(oracle.descriptor(img, x, y, float(deg)), want), (x, y, float(deg))
+
+
+def _distribute_lists(xs, ys, rs, min_x, max_x, min_y, max_y, n_target):
+    """DistributeOctTree / DivideNode (reference src/ORBextractor.cc:478-765) on Python lists:
+    insert(0) for push_front, the expandable nodes sorted by (count, creation order).  Returns the
+    indices of the kept candidates in final list order."""
+    import math
+    f32 = np.float32
+    ratio = f32(max_x - min_x) / f32(max_y - min_y)
+    n_ini = int(math.floor(float(ratio) + 0.5))                      # round(): half away from zero, ratio > 0
+    hx = f32(max_x - min_x) / f32(n_ini)
+    created = [0]
+
+    def node(ulx, uly, brx, bry):
+        created[0] += 1
+        return {"ul": (ulx, uly), "br": (brx, bry), "keys": [], "nomore": False, "id": created[0]}
+
+    nodes = [node(int(hx * f32(i)), 0, int(hx * f32(i + 1)), max_y - min_y) for i in range(n_ini)]
+    ini = list(nodes)
+    for i in range(len(xs)):
+        ini[int(f32(xs[i]) / hx)]["keys"].append(i)
+    nodes = [n for n in nodes if n["keys"]]
+    for n in nodes:
+        n["nomore"] = len(n["keys"]) == 1
+
+    def divide(n):
+        (ulx, uly), (brx, bry) = n["ul"], n["br"]
+        half_x = int(math.ceil(float(f32(brx - ulx) / f32(2))))
+        half_y = int(math.ceil(float(f32(bry - uly) / f32(2))))
+        mx, my = ulx + half_x, uly + half_y
+        kids = [node(ulx, uly, mx, my), node(mx, uly, brx, my), node(ulx, my, mx, bry), node(mx, my, brx, bry)]
+        for i in n["keys"]:
+            left, top = xs[i] < mx, ys[i] < my
+            kids[(0 if left else 1) + (0 if top else 2)]["keys"].append(i)
+        for k in kids:
+            k["nomore"] = len(k["keys"]) == 1
+        return kids
+
+    def split_into(lst, n, expandable):
+        for k in divide(n):
+            if k["keys"]:
+                lst.insert(0, k)
+                if len(k["keys"]) > 1:
+                    expandable.append(k)
+
+    finish = False
+    while not finish:
+        prev = len(nodes)
+        expandable = []
+        i = 0
+        while i < len(nodes):
+            n = nodes[i]
+            if n["nomore"]:
+                i += 1
+                continue
+            before = len(nodes)
+            split_into(nodes, n, expandable)
+            i += len(nodes) - before          # the children went in at the front
+            del nodes[i]                      # erase the parent; i now names its successor
+        if len(nodes) >= n_target or len(nodes) == prev:
+            finish = True
+        elif len(nodes) + 3 * len(expandable) > n_target:
+            while not finish:
+                prev = len(nodes)
+                todo = sorted(expandable, key=lambda n: (len(n["keys"]), n["id"]))
+                expandable = []
+                for n in reversed(todo):
+                    split_into(nodes, n, expandable)
+                    nodes.remove(n)
+                    if len(nodes) >= n_target:
+                        break
+                if len(nodes) >= n_target or len(nodes) == prev:
+                    finish = True
+    out = []
+    for n in nodes:
+        best = n["keys"][0]
+        for i in n["keys"][1:]:
+            if rs[i] > rs[best]:
+                best = i
+        out.append(best)
+    return np.array(out, np.int64)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_quadtree_equals_list_statement(oracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    w = int(rng.integers(40, 700))
+    h = int(rng.integers(max(30, (w + 3) // 4), 500))
+    if int(np.floor(w / h + 0.5)) < 1:
+        h = w
+    n = int(rng.integers(1, 4000))
+    # distinct pixels in raster order, as the detector emits them; a few large clusters so that the
+    # size-sorted phase meets equal counts
+    pix = rng.choice(w * h, size=min(n, w * h), replace=False)
+    pix.sort()
+    xs, ys = (pix % w).astype(np.int32), (pix // w).astype(np.int32)
+    rs = rng.integers(7, 60, size=len(pix)).astype(np.int32)
+    for target in (1, 5, int(rng.integers(10, 600)), 5000):
+        want = _distribute_lists(xs, ys, rs, 16, 16 + w, 16, 16 + h, target)
+        got = np.asarray(oracle.distribute(xs, ys, rs, 16, 16 + w, 16, 16 + h, target))
+        assert np.array_equal(got, want), (seed, w, h, len(pix), target)
