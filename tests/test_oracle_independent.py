@@ -271,3 +271,181 @@ def test_quadtree_equals_list_statement(oracle, seed):
         want = _distribute_lists(xs, ys, rs, 16, 16 + w, 16, 16 + h, target)
         got = np.asarray(oracle.distribute(xs, ys, rs, 16, 16 + w, 16, 16 + h, target))
         assert np.array_equal(got, want), (seed, w, h, len(pix), target)
+
+
+# ---------------------------------------------------------------- matcher: sequential-state core
+def _c_round(v):
+    """C round(): half away from zero."""
+    import math
+    return int(math.floor(abs(v) + 0.5)) * (1 if v >= 0 else -1)
+
+
+class _PyFrame:
+    """Frame grid (reference src/Frame.cc:302-317, 494-502, 211-212) and GetFeaturesInArea (:437-490)
+    on Python lists, in single precision where the reference computes in float."""
+
+    def __init__(self, kps, desc, bounds):
+        f32 = np.float32
+        self.kps, self.desc = kps, desc
+        self.min_x, self.min_y, self.max_x, self.max_y = (f32(b) for b in bounds)
+        self.inv_w = f32(64) / f32(self.max_x - self.min_x)
+        self.inv_h = f32(48) / f32(self.max_y - self.min_y)
+        self.grid = [[[] for _ in range(48)] for _ in range(64)]
+        for i in range(len(kps)):
+            px = _c_round(float(f32(f32(kps["x"][i]) - self.min_x) * self.inv_w))
+            py = _c_round(float(f32(f32(kps["y"][i]) - self.min_y) * self.inv_h))
+            if 0 <= px < 64 and 0 <= py < 48:
+                self.grid[px][py].append(i)
+
+    def in_area(self, x, y, r, min_level, max_level):
+        import math
+        f32 = np.float32
+        x, y, r = f32(x), f32(y), f32(r)
+        out = []
+        x0 = max(0, int(math.floor(float(f32(f32(x - self.min_x) - r) * self.inv_w))))
+        if x0 >= 64:
+            return out
+        x1 = min(63, int(math.ceil(float(f32(f32(x - self.min_x) + r) * self.inv_w))))
+        if x1 < 0:
+            return out
+        y0 = max(0, int(math.floor(float(f32(f32(y - self.min_y) - r) * self.inv_h))))
+        if y0 >= 48:
+            return out
+        y1 = min(47, int(math.ceil(float(f32(f32(y - self.min_y) + r) * self.inv_h))))
+        if y1 < 0:
+            return out
+        check = min_level > 0 or max_level >= 0
+        for ix in range(x0, x1 + 1):
+            for iy in range(y0, y1 + 1):
+                for i in self.grid[ix][iy]:
+                    if check:
+                        if self.kps["octave"][i] < min_level:
+                            continue
+                        if max_level >= 0 and self.kps["octave"][i] > max_level:
+                            continue
+                    if abs(f32(self.kps["x"][i]) - x) < r and abs(f32(self.kps["y"][i]) - y) < r:
+                        out.append(i)
+        return out
+
+
+def _three_maxima(sizes):
+    """ComputeThreeMaxima (reference src/ORBmatcher.cc:1849-1894)."""
+    f32 = np.float32
+    m1 = m2 = m3 = 0
+    i1 = i2 = i3 = -1
+    for i, s in enumerate(sizes):
+        if s > m1:
+            m3, m2, m1 = m2, m1, s
+            i3, i2, i1 = i2, i1, i
+        elif s > m2:
+            m3, m2 = m2, s
+            i3, i2 = i2, i
+        elif s > m3:
+            m3, i3 = s, i
+    if f32(m2) < f32(0.1) * f32(m1):
+        i2 = i3 = -1
+    elif f32(m3) < f32(0.1) * f32(m1):
+        i3 = -1
+    return i1, i2, i3
+
+
+def _search_for_initialization(f1, f2, prev, window, ratio, check_ori):
+    """ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:501-628)."""
+    f32 = np.float32
+    big = 2 ** 31 - 1
+    n1, n2 = len(f1.kps), len(f2.kps)
+    m12, m21, dist2 = [-1] * n1, [-1] * n2, [big] * n2
+    hist = [[] for _ in range(30)]
+    nmatches = 0
+    bits = np.unpackbits(f2.desc, axis=1) if n2 else None
+    for i1 in range(n1):
+        if f1.kps["octave"][i1] > 0:
+            continue
+        cand = f2.in_area(prev[i1][0], prev[i1][1], window, 0, 0)
+        if not cand:
+            continue
+        d1 = np.unpackbits(f1.desc[i1])
+        best = best2 = big
+        best_idx = -1
+        for i2 in cand:
+            d = int((d1 != bits[i2]).sum())
+            if dist2[i2] <= d:
+                continue
+            if d < best:
+                best2, best, best_idx = best, d, i2
+            elif d < best2:
+                best2 = d
+        if best <= 50 and f32(best) < f32(best2) * f32(ratio):
+            if m21[best_idx] >= 0:
+                m12[m21[best_idx]] = -1
+                nmatches -= 1
+            m12[i1], m21[best_idx], dist2[best_idx] = best_idx, i1, best
+            nmatches += 1
+            if check_ori:
+                rot = f32(f1.kps["angle"][i1]) - f32(f2.kps["angle"][best_idx])
+                if rot < 0:
+                    rot = f32(rot + f32(360))
+                b = _c_round(float(f32(rot * f32(f32(1) / f32(30)))))
+                hist[0 if b == 30 else b].append(i1)
+    if check_ori:
+        keep = _three_maxima([len(h) for h in hist])
+        for b in range(30):
+            if b in keep:
+                continue
+            for i1 in hist[b]:
+                if m12[i1] >= 0:
+                    m12[i1] = -1
+                    nmatches -= 1
+    prev = np.array(prev, np.float32).copy()
+    for i1 in range(n1):
+        if m12[i1] >= 0:
+            prev[i1] = (f2.kps["x"][m12[i1]], f2.kps["y"][m12[i1]])
+    return nmatches, np.array(m12, np.int32), prev
+
+
+def _random_frame(rng, n, protos, w=640.0, h=480.0):
+    from oracle.pyoracle import KP_DTYPE
+    k = np.zeros(n, KP_DTYPE)
+    k["x"] = rng.uniform(-4, w + 4, n).astype(np.float32)       # a few points outside the grid bounds
+    k["y"] = rng.uniform(-4, h + 4, n).astype(np.float32)
+    k["x"][::7] = np.rint(k["x"][::7])                           # integer coordinates sit on cell edges
+    k["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    k["octave"] = rng.choice([0, 0, 0, 1, 2], n)
+    k["size"], k["class_id"] = 31, -1
+    d = protos[rng.integers(0, len(protos), n)].copy()
+    flips = rng.integers(0, 256, (n, 12))
+    for i in range(n):
+        for b in flips[i, :rng.integers(0, 12)]:
+            d[i, b >> 3] ^= 1 << (b & 7)
+    return k, d
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_search_for_initialization_equals_list_statement(oracle, seed):
+    """Few descriptor prototypes with a few flipped bits: many equal distances, contested
+    candidates (the steal-back branch) and ratio-test failures."""
+    rng = np.random.default_rng(300 + seed)
+    protos = rng.integers(0, 256, (int(rng.integers(3, 40)), 32), dtype=np.uint8)
+    n1, n2 = int(rng.integers(0, 500)), int(rng.integers(1, 500))
+    k1, d1 = _random_frame(rng, n1, protos)
+    k2, d2 = _random_frame(rng, n2, protos)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    sf = 1.2 ** np.arange(8)
+    f1, f2 = oracle.FrameData(k1, d1, bounds, sf), oracle.FrameData(k2, d2, bounds, sf)
+    p1, p2 = _PyFrame(k1, d1, bounds), _PyFrame(k2, d2, bounds)
+    # grid and window queries first
+    start, items = oracle.grid_build(f2)
+    for ix in range(64):
+        for iy in range(48):
+            c = ix * 48 + iy
+            assert list(items[start[c]:start[c + 1]]) == p2.grid[ix][iy]
+    for _ in range(40):
+        x, y, r = rng.uniform(-30, 670), rng.uniform(-30, 510), rng.uniform(1, 120)
+        lv = [(-1, -1), (0, 0), (1, 2), (2, -1)][int(rng.integers(0, 4))]
+        assert list(oracle.features_in_area(f2, start, items, x, y, r, *lv)) == p2.in_area(x, y, r, *lv)
+    prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32) + rng.uniform(-20, 20, (n1, 2)).astype(np.float32)
+    for window, ratio, ori in ((100, 0.9, True), (30, 0.75, False)):
+        want = _search_for_initialization(p1, p2, prev, window, ratio, ori)
+        got = oracle.search_for_initialization(f1, f2, prev, window, ratio, ori)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        prev = got[2]                                            # second call from the updated positions
