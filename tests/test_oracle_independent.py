@@ -449,3 +449,91 @@ def test_search_for_initialization_equals_list_statement(oracle, seed):
         got = oracle.search_for_initialization(f1, f2, prev, window, ratio, ori)
         assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
         prev = got[2]                                            # second call from the updated positions
+
+
+def _search_by_projection_frames(cur, last, sf, valid, u, v, invz, has_obs, u_right, bf, th, direction, check_ori,
+                                 claimed, claimed_obs):
+    """ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono) from the projections on
+    (reference src/ORBmatcher.cc:1560-1677).  claimed[i2] = index of the last-frame point whose map
+    point the current keypoint holds (-1: none), claimed_obs[i2] = that map point has observations."""
+    f32 = np.float32
+    claimed, claimed_obs = list(claimed), list(claimed_obs)
+    hist = [[] for _ in range(30)]
+    nmatches = 0
+    cbits = np.unpackbits(cur.desc, axis=1)
+    for i in range(len(last.kps)):
+        if not valid[i] or invz[i] < 0:
+            continue
+        if u[i] < cur.min_x or u[i] > cur.max_x or v[i] < cur.min_y or v[i] > cur.max_y:
+            continue
+        octv = int(last.kps["octave"][i])
+        radius = f32(f32(th) * f32(sf[octv]))
+        if direction == 1:
+            cand = cur.in_area(u[i], v[i], radius, octv, -1)
+        elif direction == 2:
+            cand = cur.in_area(u[i], v[i], radius, 0, octv)
+        else:
+            cand = cur.in_area(u[i], v[i], radius, octv - 1, octv + 1)
+        if not cand:
+            continue
+        d1 = np.unpackbits(last.desc[i])
+        best, best_idx = 256, -1
+        for i2 in cand:
+            if claimed[i2] >= 0 and claimed_obs[i2]:
+                continue
+            if u_right[i2] > 0:
+                ur = f32(f32(u[i]) - f32(f32(bf) * f32(invz[i])))
+                if abs(f32(ur - f32(u_right[i2]))) > radius:
+                    continue
+            d = int((d1 != cbits[i2]).sum())
+            if d < best:
+                best, best_idx = d, i2
+        if best <= 100:
+            claimed[best_idx], claimed_obs[best_idx] = i, int(has_obs[i])
+            nmatches += 1
+            if check_ori:
+                rot = f32(last.kps["angle"][i]) - f32(cur.kps["angle"][best_idx])
+                if rot < 0:
+                    rot = f32(rot + f32(360))
+                b = _c_round(float(f32(rot * f32(f32(1) / f32(30)))))
+                hist[0 if b == 30 else b].append(best_idx)
+    if check_ori:
+        keep = _three_maxima([len(h) for h in hist])
+        for b in range(30):
+            if b not in keep:
+                for i2 in hist[b]:
+                    claimed[i2] = -1
+                    nmatches -= 1
+    return nmatches, np.array(claimed, np.int32)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_search_by_projection_frames_equals_list_statement(oracle, seed):
+    rng = np.random.default_rng(500 + seed)
+    protos = rng.integers(0, 256, (int(rng.integers(3, 60)), 32), dtype=np.uint8)
+    n_cur, n_last = int(rng.integers(1, 600)), int(rng.integers(1, 600))
+    kc, dc = _random_frame(rng, n_cur, protos)
+    kl, dl = _random_frame(rng, n_last, protos)
+    bounds = (0.0, 0.0, 640.0, 480.0)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    fc, fl = oracle.FrameData(kc, dc, bounds, sf), oracle.FrameData(kl, dl, bounds, sf)
+    pc, pl = _PyFrame(kc, dc, bounds), _PyFrame(kl, dl, bounds)
+    valid = (rng.uniform(size=n_last) < 0.8).astype(np.uint8)
+    # projections near current keypoints (so that windows hold candidates), some outside the image,
+    # some behind the camera
+    tgt = rng.integers(0, n_cur, n_last)
+    u = (kc["x"][tgt] + rng.uniform(-6, 6, n_last)).astype(np.float32)
+    v = (kc["y"][tgt] + rng.uniform(-6, 6, n_last)).astype(np.float32)
+    u[::17] = -50
+    invz = rng.uniform(0.05, 1.0, n_last).astype(np.float32)
+    invz[::13] = -0.1
+    has_obs = (rng.uniform(size=n_last) < 0.5).astype(np.uint8)
+    u_right = np.where(rng.uniform(size=n_cur) < 0.5, kc["x"] - rng.uniform(0, 30, n_cur), -1).astype(np.float32)
+    claimed = np.where(rng.uniform(size=n_cur) < 0.15, rng.integers(0, n_last, n_cur), -1).astype(np.int32)
+    claimed_obs = ((claimed >= 0) & (rng.uniform(size=n_cur) < 0.5)).astype(np.uint8)
+    for th, direction, ori in ((7.0, 0, True), (15.0, 1, True), (15.0, 2, False), (3.0, 0, False)):
+        want = _search_by_projection_frames(pc, pl, sf, valid, u, v, invz, has_obs, u_right, 40.0, th, direction, ori,
+                                            claimed, claimed_obs)
+        got = oracle.search_by_projection_frames(fc, fl, valid, u, v, invz, has_obs, u_right, 40.0, th, direction, ori,
+                                                 claimed=claimed, claimed_obs=claimed_obs)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]), (seed, th, direction, ori, got[0], want[0])
