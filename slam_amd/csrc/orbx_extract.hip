@@ -34,6 +34,7 @@ typedef long long i64;
 const int ORBX_PIPES = 4;
 const int EDGE_THRESHOLD = 19;  // reference src/ORBextractor.cc:53
 const int MIN_BORDER = EDGE_THRESHOLD - 3;
+const int FAST_LDS_SMALL = 5120;  // LDS comes in 1280-byte granules: four of them let 32 one-wave workgroups share a compute unit's 160 KB
 const int MAX_CELL = 59;  // largest cell side: ceil(width / floor(width/30)) < 60
 const int MAX_ROOTS = 64;
 
@@ -58,8 +59,7 @@ struct LevelGeom {
 struct Geom {
     int nlevels, w, h;
     int totalCells, totalSlots, totalSel, totalBlurTiles, totalBlurItems;
-    int fastRoiPitch, fastPlaneOff, fastQueueOff, fastLdsBytes;  // k_fast LDS carve-up
-    u32 fastRoiMagic;                                            // div_magic(fastRoiPitch)
+    int fastRoiPitch;  // k_fast: widest row pitch of its cell buffer over all levels
     i64 pyrFrameBytes, blurFrameBytes;
     LevelGeom lv[ORBX_MAX_LEVELS];
 };
@@ -948,8 +948,20 @@ __host__ __device__ __forceinline__ u32 div_magic(u32 d) { return d <= 1 ? 0u : 
 //         for every copying lane and group nFull holds rem rows
 // nk = 32-bit words per row that hold interior pixels when interior pixel 0 sits on a word
 // boundary, nWc = nk + 2 = words copied per ROI row (one before, one after).
+//   w12 = the cell's index (cell counts and the quadtree number cells level by level; the records
+//         are ordered group by group, see FastGroup)   w13..15 = 0
 struct FastCell {
-    u32 w[12];
+    u32 w[16];
+};
+
+// The cells of a pyramid are launched in up to two groups of levels, each with the LDS carve-up that
+// its own largest cell needs: LDS is handed out in granules, and the levels whose buffers fit 5120
+// bytes run 32 waves per compute unit where the largest cells of the pyramid would hold every level
+// to 25 (640x480: levels 0..3, 85 % of the cells).
+struct FastGroup {
+    int recBegin, nCells;                       // this group's slice of the cell records
+    int roiPitch, planeOff, queueOff, ldsBytes;  // ROI rows | strength plane (also the word queue) | pixel queue
+    u32 roiMagic;                               // div_magic(roiPitch)
 };
 
 // v_pk_minimum3_f16 / v_pk_maximum3_f16: three-input minimum / maximum on both 16-bit halves.
@@ -1028,23 +1040,23 @@ struct __attribute__((packed, aligned(4))) FastPair {
 template <int RPC>
 __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligned, const u8* __restrict__ pyr,
                                               const FastCell* __restrict__ cells, u32* __restrict__ cellCount,
-                                              u32* __restrict__ slots, int iniTh, int minTh) {
+                                              u32* __restrict__ slots, int iniTh, int minTh, FastGroup grp) {
     extern __shared__ __align__(16) u8 lds[];
     // LDS_U8 / LDS_U32 take LDS addresses: the array's own address (a link-time constant, 0 while it is
     // the kernel's only LDS object) is folded into every base register below, at no cost
     const u32 L0 = (u32)(size_t)(const __attribute__((address_space(3))) u8*)lds;
     u8* roi = lds;
-    u8* plane = lds + g.fastPlaneOff;
+    u8* plane = lds + grp.planeOff;
     u32* wq = (u32*)plane;  // the word queue is dead before the plane is cleared
-    u16* queue = (u16*)(lds + g.fastQueueOff);
+    u16* queue = (u16*)(lds + grp.queueOff);
     // blockIdx.x = frame: with a batch that is a multiple of 8 all cells of a frame run on one
     // XCD, so the halo rows and cache lines that neighbouring cells share come from its L2.
     const int f = blockIdx.x;
-    const int cell0 = blockIdx.y * FAST_CPW;
+    const int rec0 = grp.recBegin + blockIdx.y * FAST_CPW, recEnd = grp.recBegin + grp.nCells;
     const int lane = threadIdx.x;
     // RPC = the ROI row pitch as a compile-time constant (0: taken from the geometry): with a constant
     // pitch every ring, neighbour and row access below is one base register plus an immediate offset
-    const int RP = RPC ? RPC : g.fastRoiPitch;
+    const int RP = RPC ? RPC : grp.roiPitch;
 #ifdef ORBX_FAST_DIAG
     unsigned long long diagT[5] = {0, 0, 0, 0, 0}, diagLast = __builtin_amdgcn_s_memtime();
     int diagN1 = 0, diagN2 = 0, diagPass2 = 0, diagNW = 0, diagTotal = 0;
@@ -1070,7 +1082,6 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
         return sbase + 4 * ((int)(t >> 2) - 1);
     };
     auto issue = [&](const FastCell& C, FastPair (&v)[8]) {
-        const int rh = (C.w[0] >> 16) & 255;
         const int nWc = (int)(C.w[7] & 255), rowsW = (int)((C.w[7] >> 8) & 255);
         const int lw = (int)fastdiv((u32)lane, (u32)nWc, C.w[5]), wd = lane - lw * nWc;
         if (lw < rowsW) {
@@ -1125,12 +1136,13 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
         }
     };
 
-    FastCell C = cells[min(cell0, g.totalCells - 1)];
+    FastCell C = cells[min(rec0, recEnd - 1)];
     FastPair pre[8];
     if (aligned(C)) issue(C, pre);
     for (int ci = 0; ci < FAST_CPW; ci++) {
-        const int cell = cell0 + ci;
-        if (cell >= g.totalCells) break;
+        const int rec = rec0 + ci;
+        if (rec >= recEnd) break;
+        const int cell = (int)C.w[12];
         const int rw = (C.w[0] >> 8) & 255, rh = (C.w[0] >> 16) & 255;
         const int cellCap = C.w[3] & 0xffff;
         u32* cnt = cellCount + (i64)f * g.totalCells + cell;
@@ -1153,8 +1165,8 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
         }
         __syncthreads();
         // request the next cell's ROI now: it arrives while this cell is worked on
-        const FastCell Cn = cells[min(cell + 1, g.totalCells - 1)];
-        if (ci + 1 < FAST_CPW && cell + 1 < g.totalCells && aligned(Cn)) issue(Cn, pre);
+        const FastCell Cn = cells[min(rec + 1, recEnd - 1)];
+        if (ci + 1 < FAST_CPW && rec + 1 < recEnd && aligned(Cn)) issue(Cn, pre);
         FAST_STAMP(0);
         if (empty) {
             if (lane == 0) *cnt = 0;
@@ -1333,7 +1345,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                 int s = 0;
                 if (wi < n2) {
                     o = queue[wi];
-                    u32 q0 = o + (L0 + (u32)g.fastPlaneOff - (u32)(RP + 1));  // top-left neighbour in the plane
+                    u32 q0 = o + (L0 + (u32)grp.planeOff - (u32)(RP + 1));  // top-left neighbour in the plane
                     asm("" : "+v"(q0));
 #define PL(k) ((int)LDS_U8(q0 + (u32)(k)))
                     const int m = PL(RP + 1);
@@ -1346,7 +1358,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
                 int tot;
                 const int off = wave_excl_count(keep, &tot);
                 if (keep && total + off < cellCap) {
-                    const int yy = RPC ? (int)(o / (u32)(RPC ? RPC : 1)) : (int)__umulhi(o, g.fastRoiMagic);
+                    const int yy = RPC ? (int)(o / (u32)(RPC ? RPC : 1)) : (int)__umulhi(o, grp.roiMagic);
                     const int xx = (int)o - yy * RP;  // ROI row, byte in row
                     out[total + off] = ORBX_PACK(gx0 + xx - 4, gy0 + yy - 3, s);
                 }
@@ -1364,7 +1376,7 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
 #ifdef ORBX_FAST_DIAG
     FAST_STAMP(4);
     if (lane == 0 && d_fastDiag) {
-        unsigned long long* r = d_fastDiag + ((size_t)f * gridDim.y + blockIdx.y) * 8;
+        unsigned long long* r = d_fastDiag + ((size_t)f * g.totalCells + rec0) * 8;
         for (int i = 0; i < 5; i++) r[i] = diagT[i];
         r[5] = (unsigned long long)(u32)diagN1 | ((unsigned long long)(u32)diagN2 << 32);
         r[6] = (unsigned long long)(u32)diagTotal | ((unsigned long long)(u32)diagPass2 << 32);
@@ -2175,7 +2187,10 @@ struct orbx_handle {
     bool qtGlobal = false;   // tables too large for the LDS: they live in dNodeTables
     int qtThreads = 256;
     ResizeTap* dTaps = nullptr;  // x taps then y taps for each level >= 1
-    FastCell* dCells = nullptr;  // one record per FAST cell, all levels
+    FastCell* dCells = nullptr;  // one record per FAST cell, all levels, ordered group by group
+    std::vector<FastGroup> fastGroups;   // one launch of k_fast each
+    std::vector<int> fastLevelGroup;     // level -> group
+    bool fastOneGroup = false;           // ORBX_FAST_GROUPS=1: one launch with the buffers of the largest cell (measurement / test knob)
     size_t cellsCap = 0;
     size_t tapsCap = 0;
     size_t tapXOff[ORBX_MAX_LEVELS], tapYOff[ORBX_MAX_LEVELS], tapSOff[ORBX_MAX_LEVELS];
@@ -2439,10 +2454,50 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
             const int want = atoi(e) & ~3;
             if (want > g.fastRoiPitch && want <= 128) g.fastRoiPitch = want;
         }
-        g.fastRoiMagic = div_magic((u32)g.fastRoiPitch);
-        g.fastPlaneOff = align_up(g.fastRoiPitch * (mh + 6), 16);
-        g.fastQueueOff = g.fastPlaneOff + align_up(g.fastRoiPitch * (mh + 6), 16);
-        g.fastLdsBytes = g.fastQueueOff + align_up(2 * mw * mh + 8, 16);
+        // LDS carve-up for a set of levels (largest cell mw x mh, row pitch at least minPitch)
+        if (const char* e = getenv("ORBX_FAST_GROUPS")) h->fastOneGroup = atoi(e) == 1;
+        auto layout = [&](int mw_, int mh_, int minPitch) {
+            FastGroup G;
+            memset(&G, 0, sizeof(G));
+            G.roiPitch = std::max(4 * ((mw_ + 3) / 4 + 2), minPitch);
+            G.roiMagic = div_magic((u32)G.roiPitch);
+            G.planeOff = align_up(G.roiPitch * (mh_ + 6), 16);
+            G.queueOff = G.planeOff + align_up(G.roiPitch * (mh_ + 6), 16);
+            G.ldsBytes = G.queueOff + align_up(2 * mw_ * mh_ + 8, 16);
+            return G;
+        };
+        const bool forcedPitch = g.fastRoiPitch != 4 * ((mw + 3) / 4 + 2);
+        // Levels whose own buffers fit FAST_LDS_SMALL bytes form the first group when that buys anything:
+        // some other level needs more, and the group as a whole (its widest and its tallest cell) still fits.
+        h->fastLevelGroup.assign(g.nlevels, 0);
+        int smw = 0, smh = 0, nSmall = 0, nLarge = 0;
+        for (int l = 0; l < g.nlevels; l++) {
+            if (g.lv[l].nCells <= 0) continue;
+            if (layout(g.lv[l].wCell, g.lv[l].hCell, 0).ldsBytes <= FAST_LDS_SMALL) {
+                smw = std::max(smw, g.lv[l].wCell);
+                smh = std::max(smh, g.lv[l].hCell);
+                nSmall++;
+            } else {
+                h->fastLevelGroup[l] = 1;
+                nLarge++;
+            }
+        }
+        const bool split = !forcedPitch && !h->fastOneGroup && nSmall > 0 && nLarge > 0 &&
+                           layout(smw, smh, 0).ldsBytes <= FAST_LDS_SMALL;
+        h->fastGroups.clear();
+        if (split) {
+            int lmw = 1, lmh = 1;
+            for (int l = 0; l < g.nlevels; l++)
+                if (g.lv[l].nCells > 0 && h->fastLevelGroup[l] == 1) {
+                    lmw = std::max(lmw, g.lv[l].wCell);
+                    lmh = std::max(lmh, g.lv[l].hCell);
+                }
+            h->fastGroups.push_back(layout(smw, smh, 0));
+            h->fastGroups.push_back(layout(lmw, lmh, 0));
+        } else {
+            h->fastLevelGroup.assign(g.nlevels, 0);
+            h->fastGroups.push_back(layout(mw, mh, g.fastRoiPitch));
+        }
     }
     g.pyrFrameBytes = align_up((int)std::max<i64>(pyrOff, 64), 256);
     g.blurFrameBytes = align_up((int)blurOff, 256);
@@ -2602,7 +2657,11 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     // FAST cell records (reference src/ORBextractor.cc:799-817 for the ROI bounds)
     std::vector<FastCell> cells((size_t)g.totalCells);
     memset(cells.data(), 0, cells.size() * sizeof(FastCell));
-    for (int l = 0; l < g.nlevels; l++) {
+    int recNext = 0;
+    for (size_t gi = 0; gi < h->fastGroups.size(); gi++) {
+      h->fastGroups[gi].recBegin = recNext;
+      for (int l = 0; l < g.nlevels; l++) {
+        if (h->fastLevelGroup[l] != (int)gi) continue;
         const LevelGeom& L = g.lv[l];
         const int maxBX = L.w - MIN_BORDER, maxBY = L.h - MIN_BORDER;
         for (int c = 0; c < L.nCells; c++) {
@@ -2613,7 +2672,8 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
             const int iw = std::max(rw - 6, 1);
             const int nk = (iw + 3) / 4, nWc = nk + 2;
             auto magic = [](int d) { return d <= 1 ? 0u : (u32)(0x100000000ull / (u32)d) + 1u; };
-            FastCell& F = cells[(size_t)L.cellBase + c];
+            FastCell& F = cells[(size_t)recNext++];
+            F.w[12] = (u32)(L.cellBase + c);
             F.w[0] = (u32)l | ((u32)rw << 8) | ((u32)rh << 16) | ((u32)(iniX & 3) << 24);
             F.w[1] = (u32)iniX | ((u32)iniY << 16);
             F.w[2] = (u32)(L.slotBase + c * L.cellCap);
@@ -2640,6 +2700,11 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
                 return ORBX_ERR_UNSUPPORTED;
             }
         }
+      }
+      h->fastGroups[gi].nCells = recNext - h->fastGroups[gi].recBegin;
+      if (getenv("ORBX_VERBOSE"))
+          fprintf(stderr, "orbx: FAST group %d: %d cells, row pitch %d, %d bytes of LDS\n", (int)gi, h->fastGroups[gi].nCells,
+                  h->fastGroups[gi].roiPitch, h->fastGroups[gi].ldsBytes);
     }
     if (cells.size() > h->cellsCap) {
         free_dev(h->dCells);
@@ -2919,10 +2984,13 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     {
         StageTimer t(h, ORBX_STAGE_FAST);
         const int aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0;
-        dim3 grid(n, (g.totalCells + FAST_CPW - 1) / FAST_CPW, 1), block(64, 1, 1);
+        static const int ldsPad = getenv("ORBX_FAST_LDS_PAD") ? atoi(getenv("ORBX_FAST_LDS_PAD")) : 0;  // measurement knob: fewer waves per compute unit
+        for (const FastGroup& G : h->fastGroups) {
+        if (G.nCells <= 0) continue;
+        dim3 grid(n, (G.nCells + FAST_CPW - 1) / FAST_CPW, 1), block(64, 1, 1);
         // the kernel is instantiated for every ROI pitch a cell of 30 .. 59 pixels can have
         auto kf = k_fast<0>;
-        switch (g.fastRoiPitch) {
+        switch (G.roiPitch) {
             case 40: kf = k_fast<40>; break;
             case 44: kf = k_fast<44>; break;
             case 48: kf = k_fast<48>; break;
@@ -2934,9 +3002,10 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             default: break;
         }
         if (h->fastGenericPitch) kf = k_fast<0>;
-        hipLaunchKernelGGL(kf, grid, block, g.fastLdsBytes, st, g, img0, aligned0, (const u8*)h->dPyr,
+        hipLaunchKernelGGL(kf, grid, block, G.ldsBytes + ldsPad, st, g, img0, aligned0, (const u8*)h->dPyr,
                            (const FastCell*)h->dCells, h->dCellCount, h->dSlots, std::min(std::max(h->cfg.ini_th_fast, 0), 255),
-                           std::min(std::max(h->cfg.min_th_fast, 0), 255));
+                           std::min(std::max(h->cfg.min_th_fast, 0), 255), G);
+        }
     }
     if (lateFork) {
         const int rc = launch_blur();

@@ -271,14 +271,17 @@ def test_fast_row_pitch_forms_equal_oracle(oracle, monkeypatch, w, h, nl):
     p = oracle.params(nfeatures=600, nlevels=nl)
     want = [oracle.extract(p, imgs[f], cap=900) for f in range(2)]
     assert sum(len(k) for k, _ in want) > 0
-    for generic in ("0", "1"):
+    for generic, groups in (("0", "0"), ("1", "0"), ("0", "1")):
+        # groups "1": one launch with the buffers of the largest cell instead of one launch per group
+        # of levels (640x480: levels 0..3 and 4..7)
         monkeypatch.setenv("ORBX_FAST_GENERIC", generic)
+        monkeypatch.setenv("ORBX_FAST_GROUPS", groups)
         ex = ORBextractor(600, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=2)
         try:
             kps, desc, n = ex.extract_batch(imgs)
             for f in range(2):
                 assert_same_features(kps[f, :n[f]], desc[f, :n[f]], want[f][0], want[f][1],
-                                     "%dx%d generic=%s frame %d" % (w, h, generic, f))
+                                     "%dx%d generic=%s groups=%s frame %d" % (w, h, generic, groups, f))
         finally:
             ex.close()
 

@@ -13,11 +13,12 @@ from slam_amd import _lib  # noqa: E402
 if len(sys.argv) > 1 and sys.argv[1] != "-":
     _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 MB = int(sys.argv[2]) if len(sys.argv) > 2 else 512   # frames per pass
+NL = int(sys.argv[3]) if len(sys.argv) > 3 else 8     # pyramid levels
 from slam_amd import synth  # noqa: E402
 from slam_amd.extractor import ORBextractor  # noqa: E402
 
 B = 2048
-ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=MB)
+ex = ORBextractor(1000, 1.2, NL, 20, 7, max_width=640, max_height=480, max_batch=MB)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 ex.set_stream(st.cuda_stream)
@@ -38,4 +39,5 @@ for _ in range(3):
     ex.extract_batch_device(fr, k, d, n, cap)
 ex.synchronize()
 prof = ex.profile_read()
-print(os.path.basename(_lib.LIB_PATH), "frames per pass", MB, {name: round(1000.0 * ms / (3 * B), 4) for name, (ms, _) in prof.items()})
+print(os.path.basename(_lib.LIB_PATH), "frames per pass", MB, {name: round(1000.0 * ms / (3 * B), 4) for name, (ms, _) in prof.items()},
+      "launches", {name: n for name, (_, n) in prof.items()})
