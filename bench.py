@@ -167,7 +167,7 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from source_hash import kernel_source_hash
     src_hash = kernel_source_hash()
-    traffic, traffic_note = None, None
+    traffic, traffic_note, launches_per_pass = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -176,6 +176,7 @@ def main():
                 traffic_note = "profiles/pmc_traffic.json was taken with other kernel sources (stale): not quoted"
             elif dominant in tj and tj[dominant].get("frames_per_launch") == frames_per_launch:
                 traffic = tj[dominant]["hbm_bytes_per_launch"]
+                launches_per_pass = tj[dominant].get("launches_per_pass", 1)
         except Exception:
             traffic = None
     valu = None
@@ -203,6 +204,10 @@ def main():
                 "kernel_source_hash": src_hash}
     if traffic_note:
         roofline["traffic_note"] = traffic_note
+    if launches_per_pass and launches_per_pass != 1:
+        # a "launch" of this stage is the set of launches that covers one pass of frames (k_fast runs once per
+        # group of pyramid levels): durations, bytes and counters are sums over that set
+        roofline["launches_per_pass"] = launches_per_pass
     if valu:
         per_s = valu / (st2[dominant]["ms_per_launch"] * 1e-3)
         roofline["valu_issue"] = {"wave_instr_per_launch": int(valu), "wave_instr_per_s_serialized": round(per_s, 1),

@@ -1890,12 +1890,15 @@ __global__ void k_debug_atan2(const float* y, const float* x, float* out, int n)
     if (i < n) out[i] = fast_atan2_deg(y[i], x[i]);
 }
 
-#define DESC_KPW 8  // keypoints per wave
+#ifndef DESC_KPW
+#define DESC_KPW 8  // keypoints per wave (8 or 4)
+#endif
+#define DESC_LPV (32 / DESC_KPW)  // lanes that end up holding one moment of one keypoint after the exchange
 #define DESC_R 18            // window radius of the steered tests
 #define DESC_ROW_DW 10       // 32-bit words per window row (37 bytes + up to 3 of alignment)
 #define DESC_WIN_DW 384      // window slots in LDS: 37 * 10 = 370 used, six loads of 64 lanes
 #ifndef DESC_BATCH
-#define DESC_BATCH 8         // windows staged at a time per wave
+#define DESC_BATCH DESC_KPW  // windows staged at a time per wave
 #endif
 
 __device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -2067,12 +2070,12 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
                 V[t] = keep + __shfl_xor(send, dist);
             }
         }
-        V[0] += __shfl_xor(V[0], 2);
-        V[0] += __shfl_xor(V[0], 1);
+#pragma unroll
+        for (int d = DESC_LPV / 2; d >= 1; d >>= 1) V[0] += __shfl_xor(V[0], d);
     }
-    // lanes 8j..8j+3 hold m10 of keypoint j, lanes 8j+4..8j+7 its m01
-    const int other = __shfl_xor(V[0], 4);
-    const int m10 = (lane & 4) ? other : V[0], m01 = (lane & 4) ? V[0] : other;
+    // with L = DESC_LPV: lanes 2Lj .. 2Lj+L-1 hold m10 of keypoint j, lanes 2Lj+L .. 2Lj+2L-1 its m01
+    const int other = __shfl_xor(V[0], DESC_LPV);
+    const int m10 = (lane & DESC_LPV) ? other : V[0], m01 = (lane & DESC_LPV) ? V[0] : other;
     const float factorPI = (float)(M_PI / 180.f);
     const float angleV = fast_atan2_deg((float)m01, (float)m10);
     float aV, bV;
@@ -2094,7 +2097,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, ImgRef img0, const u8*
             const int s = sBase + j;
             if (s >= total) break;
             const int l = readlane_i(myL, j), x = readlane_i(myX, j), y = readlane_i(myY, j), resp = readlane_i(myR, j);
-            const float a = readlane_f(aV, 8 * j), b = readlane_f(bV, 8 * j), angle = readlane_f(angleV, 8 * j);
+            const float a = readlane_f(aV, 2 * DESC_LPV * j), b = readlane_f(bV, 2 * DESC_LPV * j), angle = readlane_f(angleV, 2 * DESC_LPV * j);
             // Byte address of the keypoint in its LDS window.  Rounding to nearest-even is done by adding
             // 1.5 * 2^23: the sum's bit pattern is 0x4B400000 + round(v) for |v| < 2^22, and a 24-bit
             // multiply-add on the patterns gives 40 * row + column plus a constant folded into the base.

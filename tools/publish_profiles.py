@@ -30,12 +30,13 @@ for k, t in summ["traffic"].items():
         continue
     if k == "k_resize_stream" and "k_pyramid_frame" in summ["traffic"]:
         continue                                 # the benchmark batch goes through the one-launch pyramid
-    mult = 7 if k == "k_resize_stream" else 1   # seven levels per pass
-    out[stage_of[k]] = {"kernel": k + (" (7 launches, summed)" if mult > 1 else ""),
-                        "hbm_bytes_per_launch": t["hbm_bytes_per_launch"] * mult,
+    lpp = t.get("launches_per_pass", 1)         # the counters are already summed over the launches of a pass
+    out[stage_of[k]] = {"kernel": k + (" (%g launches per pass, summed)" % lpp if lpp != 1 else ""),
+                        "hbm_bytes_per_launch": t["hbm_bytes_per_launch"],
+                        "launches_per_pass": lpp,
                         "frames_per_launch": t["frames_per_launch"],
-                        "read_bytes_corrected": t["read_bytes_corrected"] * mult,
-                        "write_bytes": t["write_bytes"] * mult}
+                        "read_bytes_corrected": t["read_bytes_corrected"],
+                        "write_bytes": t["write_bytes"]}
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from source_hash import kernel_source_hash  # noqa: E402
 out["source_hash"] = kernel_source_hash()

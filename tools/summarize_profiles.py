@@ -40,11 +40,15 @@ def kernel_table(sub, out_name):
         k = short(r["Kernel_Name"])
         per[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size_X"])
+    # a pass of the extractor launches most kernels once; k_fast goes once per group of levels, so the
+    # durations are also given per pass (passes = launches of the descriptor kernel)
+    passes = len(per.get("k_describe", [])) or min(len(v) for v in per.values())
     with open(os.path.join(dst, out_name), "w") as f:
-        f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,vgpr,sgpr,lds_bytes,workgroup\n")
+        f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,vgpr,sgpr,lds_bytes,workgroup,launches_per_pass,ns_per_pass\n")
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-            f.write("%s,%d,%d,%.1f,%d,%d,%s,%s,%s,%s\n" % ((k, len(v), sum(v), sum(v) / len(v), min(v), max(v)) + meta[k]))
-            res[k] = {"calls": len(v), "avg_ns": sum(v) / len(v)}
+            f.write("%s,%d,%d,%.1f,%d,%d,%s,%s,%s,%s,%.2f,%.1f\n" % ((k, len(v), sum(v), sum(v) / len(v), min(v), max(v)) + meta[k] +
+                                                                (len(v) / passes, sum(v) / passes)))
+            res[k] = {"calls": len(v), "avg_ns": sum(v) / len(v), "launches_per_pass": len(v) / passes, "ns_per_pass": sum(v) / passes}
     return res
 
 
@@ -61,10 +65,13 @@ for kind, sub, pre in (("FETCH_SIZE", "fetch", "f"), ("WRITE_SIZE", "write", "w"
         if r.get("Counter_Name") != kind or not mine(r["Kernel_Name"]):
             continue
         acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    passes = len(acc.get("k_describe", [])) or 1
     for k, v in acc.items():
-        # the first half of the launches are the warm-up step; all launches are identical in shape
-        traffic.setdefault(k, {})[kind + "_KiB_per_launch"] = sum(v) / len(v)
+        # the first half of the launches are the warm-up step; the passes are identical in shape.  Counters
+        # are summed per pass: k_fast is launched once per group of levels
+        traffic.setdefault(k, {})[kind + "_KiB_per_launch"] = sum(v) / passes
         traffic[k]["launches_" + kind] = len(v)
+        traffic[k]["launches_per_pass"] = len(v) / passes
 for k, t in traffic.items():
     rd = t.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024.0 * 2.0
     wr = t.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024.0
