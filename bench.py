@@ -61,6 +61,10 @@ def parse():
 
 
 def main():
+    if os.environ.get("ORBX_BENCH_WATCHDOG"):
+        # diagnostic: after that many seconds every thread's Python stack goes to stderr (the run continues)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ORBX_BENCH_WATCHDOG"]), repeat=False)
     args = parse()
     from slam_amd import dist as sdist
     from slam_amd import synth
@@ -81,6 +85,10 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # scalars exchanged between ranks live on the GPU under RCCL and on the host under gloo (a rehearsal of
+    # several ranks on one GPU): gloo's handling of device tensors stalled now and then in that setting
+    red_dev = dev if (world > 1 and dist.get_backend() == "nccl") else torch.device("cpu")
 
     B = args.frames
     ex = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, max_width=W, max_height=H,
@@ -122,7 +130,7 @@ def main():
         ex.profile_enable(False)
         prof = ex.profile_read()
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, prof
@@ -329,7 +337,7 @@ def main():
                 barrier()
                 dt = time.perf_counter() - t1
                 if world > 1:
-                    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                    t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     dt = float(t.item())
                 return float(nq_l * world) * float(NT) * reps / dt
@@ -337,7 +345,7 @@ def main():
             rate = time_search(q_l, t_l)
             accepted = int(accept.sum().item())
             if world > 1:
-                ta = torch.tensor([accepted], dtype=torch.int64, device=dev)
+                ta = torch.tensor([accepted], dtype=torch.int64, device=red_dev)
                 dist.all_reduce(ta)
                 accepted = int(ta.item())
             # worst case for the scan's skip of the top-2 update: distances fall along the train rows

@@ -69,18 +69,31 @@ def knn2_sharded(q_local, t_local, t_offset, local_knn2, merge=merge_partials, g
     nq = q_local.shape[0]
     if world == 1:
         return local_knn2(q_local, t_local, t_offset)
-    q_all = torch.empty((world * nq, 32), dtype=torch.uint8, device=q_local.device)
-    dist.all_gather_into_tensor(q_all, q_local.contiguous(), group=group)
+    rccl = dist.get_backend(group) == "nccl"
+
+    def gather(x):
+        """All ranks' x, concatenated along dimension 0.  Under gloo (rehearsals of several ranks on one
+        GPU, CPU tests) the exchange goes through host tensors: gloo's handling of device tensors
+        stalled now and then when two ranks shared a GPU."""
+        if rccl or not x.is_cuda:
+            out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+            return out
+        h = x.contiguous().cpu()
+        out = torch.empty((world * h.shape[0],) + tuple(h.shape[1:]), dtype=h.dtype)
+        dist.all_gather_into_tensor(out, h, group=group)
+        return out.to(x.device)
+
+    q_all = gather(q_local)
     idx, d, s = local_knn2(q_all, t_local, t_offset)
     mine = torch.stack([idx, d, s], dim=1).to(torch.int32).reshape(world, nq, 3).contiguous()
-    if dist.get_backend(group) == "nccl":
+    if rccl:
         # slice j of every rank's partials goes to rank j: one all-to-all over xGMI
         recv = torch.empty_like(mine)
         dist.all_to_all_single(recv, mine, group=group)
     else:
         # gloo has no all-to-all: gather everything and keep this rank's slice
-        full = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(full, mine.reshape(-1), group=group)
+        full = gather(mine.reshape(1, -1))
         recv = full.reshape(world, world, nq, 3)[:, rank].contiguous()
     acc = (recv[0, :, 0].contiguous(), recv[0, :, 1].contiguous(), recv[0, :, 2].contiguous())
     for r in range(1, world):
