@@ -296,6 +296,20 @@ def main():
     if world > 1 and rank == 0:
         print(json.dumps(out), flush=True)
         headline_printed = True
+    guard = None
+    if world > 1 and not args.no_hamming:
+        # The headline line is out.  The leg below has a collective exchange: should it ever stall (a rank
+        # lost, a fabric problem), every rank ends its process after ORBX_BENCH_LEG_TIMEOUT seconds
+        # (default 300) with status 0 instead of holding the job until something kills it.
+        import threading
+
+        def _give_up():
+            print("bench: the multi-rank Hamming leg exceeded its time limit; ending without it", file=sys.stderr, flush=True)
+            os._exit(0)
+
+        guard = threading.Timer(float(os.environ.get("ORBX_BENCH_LEG_TIMEOUT", "300")), _give_up)
+        guard.daemon = True
+        guard.start()
     if not args.no_hamming:
         try:
             m = ORBmatcher(0.6, True, device=local_rank)
@@ -386,6 +400,8 @@ def main():
 
         except Exception as e:  # noqa: BLE001
             out["hamming"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if guard is not None:
+        guard.cancel()
     # ---- windowed matcher throughput: frame-to-frame SearchByProjection over many independent pairs
     # in one call (each frame against itself, projections = keypoint positions + 1 px noise).
     if rank == 0 and world == 1 and not args.no_hamming:
