@@ -2192,8 +2192,10 @@ struct orbx_handle {
     ResizeTap* dTaps = nullptr;  // x taps then y taps for each level >= 1
     FastCell* dCells = nullptr;  // one record per FAST cell, all levels, ordered group by group
     std::vector<FastGroup> fastGroups;   // one launch of k_fast each
+    FastGroup fastWhole;                 // the same cells as one launch with the buffers of the largest cell
     std::vector<int> fastLevelGroup;     // level -> group
     bool fastOneGroup = false;           // ORBX_FAST_GROUPS=1: one launch with the buffers of the largest cell (measurement / test knob)
+    bool fastAlwaysSplit = false;        // ORBX_FAST_GROUPS=2: the level groups also for passes too small to fill the GPU (test knob)
     size_t cellsCap = 0;
     size_t tapsCap = 0;
     size_t tapXOff[ORBX_MAX_LEVELS], tapYOff[ORBX_MAX_LEVELS], tapSOff[ORBX_MAX_LEVELS];
@@ -2458,7 +2460,10 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
             if (want > g.fastRoiPitch && want <= 128) g.fastRoiPitch = want;
         }
         // LDS carve-up for a set of levels (largest cell mw x mh, row pitch at least minPitch)
-        if (const char* e = getenv("ORBX_FAST_GROUPS")) h->fastOneGroup = atoi(e) == 1;
+        if (const char* e = getenv("ORBX_FAST_GROUPS")) {
+            h->fastOneGroup = atoi(e) == 1;
+            h->fastAlwaysSplit = atoi(e) == 2;
+        }
         auto layout = [&](int mw_, int mh_, int minPitch) {
             FastGroup G;
             memset(&G, 0, sizeof(G));
@@ -2488,6 +2493,7 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         const bool split = !forcedPitch && !h->fastOneGroup && nSmall > 0 && nLarge > 0 &&
                            layout(smw, smh, 0).ldsBytes <= FAST_LDS_SMALL;
         h->fastGroups.clear();
+        h->fastWhole = layout(mw, mh, g.fastRoiPitch);  // all cells in one launch: passes too small to fill the GPU
         if (split) {
             int lmw = 1, lmh = 1;
             for (int l = 0; l < g.nlevels; l++)
@@ -2705,6 +2711,8 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         }
       }
       h->fastGroups[gi].nCells = recNext - h->fastGroups[gi].recBegin;
+      h->fastWhole.recBegin = 0;
+      h->fastWhole.nCells = recNext;
       if (getenv("ORBX_VERBOSE"))
           fprintf(stderr, "orbx: FAST group %d: %d cells, row pitch %d, %d bytes of LDS\n", (int)gi, h->fastGroups[gi].nCells,
                   h->fastGroups[gi].roiPitch, h->fastGroups[gi].ldsBytes);
@@ -2988,7 +2996,13 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         StageTimer t(h, ORBX_STAGE_FAST);
         const int aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0;
         static const int ldsPad = getenv("ORBX_FAST_LDS_PAD") ? atoi(getenv("ORBX_FAST_LDS_PAD")) : 0;  // measurement knob: fewer waves per compute unit
-        for (const FastGroup& G : h->fastGroups) {
+        // Grouping buys waves per compute unit, which only matters when there are waves to fill the GPU with
+        // (256 compute units x 32); below that one launch is cheaper than two (one 640x480 frame: 190 against 199 us)
+        const bool whole = h->fastGroups.size() > 1 && !h->fastAlwaysSplit && (i64)n * g.totalCells < 4 * 8192;
+        const FastGroup* groups = whole ? &h->fastWhole : h->fastGroups.data();
+        const size_t ngroups = whole ? 1 : h->fastGroups.size();
+        for (size_t gi = 0; gi < ngroups; gi++) {
+        const FastGroup& G = groups[gi];
         if (G.nCells <= 0) continue;
         dim3 grid(n, (G.nCells + FAST_CPW - 1) / FAST_CPW, 1), block(64, 1, 1);
         // the kernel is instantiated for every ROI pitch a cell of 30 .. 59 pixels can have

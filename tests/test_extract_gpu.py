@@ -271,9 +271,10 @@ def test_fast_row_pitch_forms_equal_oracle(oracle, monkeypatch, w, h, nl):
     p = oracle.params(nfeatures=600, nlevels=nl)
     want = [oracle.extract(p, imgs[f], cap=900) for f in range(2)]
     assert sum(len(k) for k, _ in want) > 0
-    for generic, groups in (("0", "0"), ("1", "0"), ("0", "1")):
-        # groups "1": one launch with the buffers of the largest cell instead of one launch per group
-        # of levels (640x480: levels 0..3 and 4..7)
+    for generic, groups in (("0", "2"), ("1", "2"), ("0", "1"), ("0", "0")):
+        # groups "2": one launch per group of levels (640x480: levels 0..3 and 4..7) whatever the batch;
+        # "1": one launch with the buffers of the largest cell; "0": the library's choice (one launch
+        # for a batch this small)
         monkeypatch.setenv("ORBX_FAST_GENERIC", generic)
         monkeypatch.setenv("ORBX_FAST_GROUPS", groups)
         ex = ORBextractor(600, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=2)
