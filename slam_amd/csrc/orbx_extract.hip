@@ -2668,54 +2668,54 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
     memset(cells.data(), 0, cells.size() * sizeof(FastCell));
     int recNext = 0;
     for (size_t gi = 0; gi < h->fastGroups.size(); gi++) {
-      h->fastGroups[gi].recBegin = recNext;
-      for (int l = 0; l < g.nlevels; l++) {
-        if (h->fastLevelGroup[l] != (int)gi) continue;
-        const LevelGeom& L = g.lv[l];
-        const int maxBX = L.w - MIN_BORDER, maxBY = L.h - MIN_BORDER;
-        for (int c = 0; c < L.nCells; c++) {
-            const int ci = c / L.nCols, cj = c - ci * L.nCols;
-            const int iniX = MIN_BORDER + cj * L.wCell, iniY = MIN_BORDER + ci * L.hCell;
-            const int rw = std::max(std::min(iniX + L.wCell + 6, maxBX) - iniX, 0);
-            const int rh = std::max(std::min(iniY + L.hCell + 6, maxBY) - iniY, 0);
-            const int iw = std::max(rw - 6, 1);
-            const int nk = (iw + 3) / 4, nWc = nk + 2;
-            auto magic = [](int d) { return d <= 1 ? 0u : (u32)(0x100000000ull / (u32)d) + 1u; };
-            FastCell& F = cells[(size_t)recNext++];
-            F.w[12] = (u32)(L.cellBase + c);
-            F.w[0] = (u32)l | ((u32)rw << 8) | ((u32)rh << 16) | ((u32)(iniX & 3) << 24);
-            F.w[1] = (u32)iniX | ((u32)iniY << 16);
-            F.w[2] = (u32)(L.slotBase + c * L.cellCap);
-            F.w[3] = (u32)L.cellCap | ((u32)nk << 16) | ((u32)(64 / nk) << 24);
-            F.w[4] = (u32)(cj * L.wCell + 3) | ((u32)(ci * L.hCell + 3) << 16);
-            F.w[5] = magic(nWc);
-            F.w[6] = magic(nk);
-            F.w[7] = (u32)nWc | ((u32)(64 / nWc) << 8);
-            F.w[8] = l > 0 ? (u32)(L.pyrOff + (i64)iniY * L.pyrPitch + (iniX & ~3)) : 0u;
-            F.w[9] = (u32)L.pyrPitch;
-            F.w[10] = magic(rw);
-            {  // ROI rows are copied in groups of rowsW rows, the first 8 groups through registers
-                const int rowsW = 64 / nWc;
-                const int nFull = std::min(rh / rowsW, 8);
-                const int rem = nFull < 8 ? rh - nFull * rowsW : 0;
-                F.w[11] = (u32)nFull | ((u32)rem << 8);
-            }
-            if (l > 0 && L.pyrOff + (i64)L.pyrPitch * L.h > 0xFFFFFFFFll) {
-                orbx_set_error("internal: pyramid block exceeds 4 GiB");
-                return ORBX_ERR_UNSUPPORTED;
-            }
-            if (L.cellCap > 0xffff || rw > 255 || rh > 255) {
-                orbx_set_error("internal: cell record overflow");
-                return ORBX_ERR_UNSUPPORTED;
+        h->fastGroups[gi].recBegin = recNext;
+        for (int l = 0; l < g.nlevels; l++) {
+            if (h->fastLevelGroup[l] != (int)gi) continue;
+            const LevelGeom& L = g.lv[l];
+            const int maxBX = L.w - MIN_BORDER, maxBY = L.h - MIN_BORDER;
+            for (int c = 0; c < L.nCells; c++) {
+                const int ci = c / L.nCols, cj = c - ci * L.nCols;
+                const int iniX = MIN_BORDER + cj * L.wCell, iniY = MIN_BORDER + ci * L.hCell;
+                const int rw = std::max(std::min(iniX + L.wCell + 6, maxBX) - iniX, 0);
+                const int rh = std::max(std::min(iniY + L.hCell + 6, maxBY) - iniY, 0);
+                const int iw = std::max(rw - 6, 1);
+                const int nk = (iw + 3) / 4, nWc = nk + 2;
+                auto magic = [](int d) { return d <= 1 ? 0u : (u32)(0x100000000ull / (u32)d) + 1u; };
+                FastCell& F = cells[(size_t)recNext++];
+                F.w[12] = (u32)(L.cellBase + c);
+                F.w[0] = (u32)l | ((u32)rw << 8) | ((u32)rh << 16) | ((u32)(iniX & 3) << 24);
+                F.w[1] = (u32)iniX | ((u32)iniY << 16);
+                F.w[2] = (u32)(L.slotBase + c * L.cellCap);
+                F.w[3] = (u32)L.cellCap | ((u32)nk << 16) | ((u32)(64 / nk) << 24);
+                F.w[4] = (u32)(cj * L.wCell + 3) | ((u32)(ci * L.hCell + 3) << 16);
+                F.w[5] = magic(nWc);
+                F.w[6] = magic(nk);
+                F.w[7] = (u32)nWc | ((u32)(64 / nWc) << 8);
+                F.w[8] = l > 0 ? (u32)(L.pyrOff + (i64)iniY * L.pyrPitch + (iniX & ~3)) : 0u;
+                F.w[9] = (u32)L.pyrPitch;
+                F.w[10] = magic(rw);
+                {  // ROI rows are copied in groups of rowsW rows, the first 8 groups through registers
+                    const int rowsW = 64 / nWc;
+                    const int nFull = std::min(rh / rowsW, 8);
+                    const int rem = nFull < 8 ? rh - nFull * rowsW : 0;
+                    F.w[11] = (u32)nFull | ((u32)rem << 8);
+                }
+                if (l > 0 && L.pyrOff + (i64)L.pyrPitch * L.h > 0xFFFFFFFFll) {
+                    orbx_set_error("internal: pyramid block exceeds 4 GiB");
+                    return ORBX_ERR_UNSUPPORTED;
+                }
+                if (L.cellCap > 0xffff || rw > 255 || rh > 255) {
+                    orbx_set_error("internal: cell record overflow");
+                    return ORBX_ERR_UNSUPPORTED;
+                }
             }
         }
-      }
-      h->fastGroups[gi].nCells = recNext - h->fastGroups[gi].recBegin;
-      h->fastWhole.recBegin = 0;
-      h->fastWhole.nCells = recNext;
-      if (getenv("ORBX_VERBOSE"))
-          fprintf(stderr, "orbx: FAST group %d: %d cells, row pitch %d, %d bytes of LDS\n", (int)gi, h->fastGroups[gi].nCells,
-                  h->fastGroups[gi].roiPitch, h->fastGroups[gi].ldsBytes);
+        h->fastGroups[gi].nCells = recNext - h->fastGroups[gi].recBegin;
+        h->fastWhole.recBegin = 0;
+        h->fastWhole.nCells = recNext;
+        if (getenv("ORBX_VERBOSE"))
+            fprintf(stderr, "orbx: FAST group %d: %d cells, row pitch %d, %d bytes of LDS\n", (int)gi, h->fastGroups[gi].nCells,
+                    h->fastGroups[gi].roiPitch, h->fastGroups[gi].ldsBytes);
     }
     if (cells.size() > h->cellsCap) {
         free_dev(h->dCells);
@@ -2910,83 +2910,83 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     const bool lateFork = fork && h->forkBlur == 2;
     hipStream_t bst = fork ? h->auxStream : st;
     auto launch_blur = [&]() -> int {
-    if (fork) {
-        ORBX_HIP_CHECK(hipEventRecord(h->evPyramid, st));
-        ORBX_HIP_CHECK(hipStreamWaitEvent(h->auxStream, h->evPyramid, 0));
-    }
-    {
-        StageTimer t(h, ORBX_STAGE_BLUR, bst);
-        // Level 0 is the caller's buffer: the streaming kernel reads it as aligned 32-bit
-        // words, so it needs 4-byte aligned rows that hold the last word of the row in full.
-        const bool aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0 &&
-                              img0.pitch >= align_up(g.w, 4) && g.h >= 4 && g.w >= 4;
-        const int first = aligned0 ? 0 : 1;
-        if (!aligned0) {
-            dim3 grid(g.lv[0].blurTiles, n, 1), block(256, 1, 1);
-            hipLaunchKernelGGL(k_blur, grid, block, 0, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
-                               h->gaussK[1], h->gaussK[2], h->gaussK[3], 0, h->cfg.blur_variant == 2 ? 1 : 0);
+        if (fork) {
+            ORBX_HIP_CHECK(hipEventRecord(h->evPyramid, st));
+            ORBX_HIP_CHECK(hipStreamWaitEvent(h->auxStream, h->evPyramid, 0));
         }
-        for (int l = 1; l < g.nlevels; l++) {
-            if (g.lv[l].h >= 4 && g.lv[l].w >= 4) continue;
-            dim3 grid(g.lv[l].blurTiles, n, 1), block(256, 1, 1);
-            hipLaunchKernelGGL(k_blur, grid, block, 0, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
-                               h->gaussK[1], h->gaussK[2], h->gaussK[3], g.lv[l].blurTileBase, h->cfg.blur_variant == 2 ? 1 : 0);
-        }
-        const int itemBegin = g.lv[first].blurItemBase;
-        if (first < g.nlevels && g.totalBlurItems > itemBegin) {
-            // blockIdx.x counts from the first level's item base
-            Geom gs = g;
-            for (int l = first; l < g.nlevels; l++) gs.lv[l].blurItemBase -= itemBegin;
-            // lane offsets are 32-bit: K frames of either image must stay below 2^31 bytes
-            const bool rowsOk = h->blurRows && (u64)img0.frameStride * 64 < 0x7FFFFFFFull && (u64)g.pyrFrameBytes * 64 < 0x7FFFFFFFull &&
-                                (u64)g.blurFrameBytes * 64 < 0x7FFFFFFFull;
-            if (rowsOk) {
-                // one lane split (W column groups x 64 / W frames) for all levels: the one with the fewest idle lanes
-                BlurRowsArgs A;
-                memset(&A, 0, sizeof(A));
-                // (64 x 1 or 32 x 2: narrower rows per frame cost more in the memory pipeline than idle lanes do,
-                // 0.58 and 0.81 us per frame at 16 x 4 and 8 x 8 against 0.51 at 32 x 2 for 640x480)
-                double bestEff = -1;
-                for (int lw = 6; lw >= 5; lw--) {
-                    const int Wd = 1 << lw, K = 64 >> lw;
-                    double used = 0, slots = 0;
-                    for (int l = first; l < g.nlevels; l++) {
-                        if (g.lv[l].h < 4 || g.lv[l].w < 4) continue;
-                        used += (double)g.lv[l].blurGroups * g.lv[l].h * n;
-                        slots += (double)((g.lv[l].blurGroups + Wd - 1) / Wd) * Wd * g.lv[l].h * ((n + K - 1) / K) * K;
+        {
+            StageTimer t(h, ORBX_STAGE_BLUR, bst);
+            // Level 0 is the caller's buffer: the streaming kernel reads it as aligned 32-bit
+            // words, so it needs 4-byte aligned rows that hold the last word of the row in full.
+            const bool aligned0 = ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0 &&
+                                  img0.pitch >= align_up(g.w, 4) && g.h >= 4 && g.w >= 4;
+            const int first = aligned0 ? 0 : 1;
+            if (!aligned0) {
+                dim3 grid(g.lv[0].blurTiles, n, 1), block(256, 1, 1);
+                hipLaunchKernelGGL(k_blur, grid, block, 0, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                                   h->gaussK[1], h->gaussK[2], h->gaussK[3], 0, h->cfg.blur_variant == 2 ? 1 : 0);
+            }
+            for (int l = 1; l < g.nlevels; l++) {
+                if (g.lv[l].h >= 4 && g.lv[l].w >= 4) continue;
+                dim3 grid(g.lv[l].blurTiles, n, 1), block(256, 1, 1);
+                hipLaunchKernelGGL(k_blur, grid, block, 0, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                                   h->gaussK[1], h->gaussK[2], h->gaussK[3], g.lv[l].blurTileBase, h->cfg.blur_variant == 2 ? 1 : 0);
+            }
+            const int itemBegin = g.lv[first].blurItemBase;
+            if (first < g.nlevels && g.totalBlurItems > itemBegin) {
+                // blockIdx.x counts from the first level's item base
+                Geom gs = g;
+                for (int l = first; l < g.nlevels; l++) gs.lv[l].blurItemBase -= itemBegin;
+                // lane offsets are 32-bit: K frames of either image must stay below 2^31 bytes
+                const bool rowsOk = h->blurRows && (u64)img0.frameStride * 64 < 0x7FFFFFFFull && (u64)g.pyrFrameBytes * 64 < 0x7FFFFFFFull &&
+                                    (u64)g.blurFrameBytes * 64 < 0x7FFFFFFFull;
+                if (rowsOk) {
+                    // one lane split (W column groups x 64 / W frames) for all levels: the one with the fewest idle lanes
+                    BlurRowsArgs A;
+                    memset(&A, 0, sizeof(A));
+                    // (64 x 1 or 32 x 2: narrower rows per frame cost more in the memory pipeline than idle lanes do,
+                    // 0.58 and 0.81 us per frame at 16 x 4 and 8 x 8 against 0.51 at 32 x 2 for 640x480)
+                    double bestEff = -1;
+                    for (int lw = 6; lw >= 5; lw--) {
+                        const int Wd = 1 << lw, K = 64 >> lw;
+                        double used = 0, slots = 0;
+                        for (int l = first; l < g.nlevels; l++) {
+                            if (g.lv[l].h < 4 || g.lv[l].w < 4) continue;
+                            used += (double)g.lv[l].blurGroups * g.lv[l].h * n;
+                            slots += (double)((g.lv[l].blurGroups + Wd - 1) / Wd) * Wd * g.lv[l].h * ((n + K - 1) / K) * K;
+                        }
+                        const double eff = slots > 0 ? used / slots : 0;
+                        if (eff > bestEff + 1e-9) {
+                            bestEff = eff;
+                            A.logW = lw;
+                        }
                     }
-                    const double eff = slots > 0 ? used / slots : 0;
-                    if (eff > bestEff + 1e-9) {
-                        bestEff = eff;
-                        A.logW = lw;
+                    if (h->blurLogW >= 3 && h->blurLogW <= 6) A.logW = h->blurLogW;
+                    const int Wd = 1 << A.logW, K = 64 >> A.logW;
+                    int tasks = 0;
+                    for (int l = 0; l < g.nlevels; l++) {
+                        A.taskBase[l] = tasks;
+                        A.chunks[l] = std::max((g.lv[l].blurGroups + Wd - 1) / Wd, 1);
+                        if (l >= first && g.lv[l].h >= 4 && g.lv[l].w >= 4) tasks += A.chunks[l] * g.lv[l].blurBands;
                     }
+                    A.taskBase[g.nlevels] = tasks;
+                    A.firstLevel = first;
+                    dim3 grid((n + K - 1) / K, (tasks + 3) / 4, 1), block(256, 1, 1);
+                    auto kb = h->cfg.blur_variant == 2 ? k_blur_rows<true> : k_blur_rows<false>;
+                    hipLaunchKernelGGL(kb, grid, block, h->blurLds, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0], h->gaussK[1],
+                                       h->gaussK[2], h->gaussK[3], A, n);
+                } else {
+                    dim3 grid(n, (g.totalBlurItems - itemBegin + 255) / 256, 1), block(256, 1, 1);
+                    auto kb = h->cfg.blur_variant == 2 ? k_blur_stream<true> : k_blur_stream<false>;
+                    hipLaunchKernelGGL(kb, grid, block, h->blurLds, bst, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
+                                       h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
                 }
-                if (h->blurLogW >= 3 && h->blurLogW <= 6) A.logW = h->blurLogW;
-                const int Wd = 1 << A.logW, K = 64 >> A.logW;
-                int tasks = 0;
-                for (int l = 0; l < g.nlevels; l++) {
-                    A.taskBase[l] = tasks;
-                    A.chunks[l] = std::max((g.lv[l].blurGroups + Wd - 1) / Wd, 1);
-                    if (l >= first && g.lv[l].h >= 4 && g.lv[l].w >= 4) tasks += A.chunks[l] * g.lv[l].blurBands;
-                }
-                A.taskBase[g.nlevels] = tasks;
-                A.firstLevel = first;
-                dim3 grid((n + K - 1) / K, (tasks + 3) / 4, 1), block(256, 1, 1);
-                auto kb = h->cfg.blur_variant == 2 ? k_blur_rows<true> : k_blur_rows<false>;
-                hipLaunchKernelGGL(kb, grid, block, h->blurLds, bst, g, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0], h->gaussK[1],
-                                   h->gaussK[2], h->gaussK[3], A, n);
-            } else {
-                dim3 grid(n, (g.totalBlurItems - itemBegin + 255) / 256, 1), block(256, 1, 1);
-                auto kb = h->cfg.blur_variant == 2 ? k_blur_stream<true> : k_blur_stream<false>;
-                hipLaunchKernelGGL(kb, grid, block, h->blurLds, bst, gs, img0, (const u8*)h->dPyr, h->dBlur, h->gaussK[0],
-                                   h->gaussK[1], h->gaussK[2], h->gaussK[3], first);
             }
         }
-    }
-    if (fork) {
-        ORBX_HIP_CHECK(hipEventRecord(h->evBlur, h->auxStream));
-    }
-    return ORBX_OK;
+        if (fork) {
+            ORBX_HIP_CHECK(hipEventRecord(h->evBlur, h->auxStream));
+        }
+        return ORBX_OK;
     };
     if (!lateFork) {
         const int rc = launch_blur();
@@ -3002,26 +3002,26 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         const FastGroup* groups = whole ? &h->fastWhole : h->fastGroups.data();
         const size_t ngroups = whole ? 1 : h->fastGroups.size();
         for (size_t gi = 0; gi < ngroups; gi++) {
-        const FastGroup& G = groups[gi];
-        if (G.nCells <= 0) continue;
-        dim3 grid(n, (G.nCells + FAST_CPW - 1) / FAST_CPW, 1), block(64, 1, 1);
-        // the kernel is instantiated for every ROI pitch a cell of 30 .. 59 pixels can have
-        auto kf = k_fast<0>;
-        switch (G.roiPitch) {
-            case 40: kf = k_fast<40>; break;
-            case 44: kf = k_fast<44>; break;
-            case 48: kf = k_fast<48>; break;
-            case 52: kf = k_fast<52>; break;
-            case 56: kf = k_fast<56>; break;
-            case 60: kf = k_fast<60>; break;
-            case 64: kf = k_fast<64>; break;
-            case 68: kf = k_fast<68>; break;
-            default: break;
-        }
-        if (h->fastGenericPitch) kf = k_fast<0>;
-        hipLaunchKernelGGL(kf, grid, block, G.ldsBytes + ldsPad, st, g, img0, aligned0, (const u8*)h->dPyr,
-                           (const FastCell*)h->dCells, h->dCellCount, h->dSlots, std::min(std::max(h->cfg.ini_th_fast, 0), 255),
-                           std::min(std::max(h->cfg.min_th_fast, 0), 255), G);
+            const FastGroup& G = groups[gi];
+            if (G.nCells <= 0) continue;
+            dim3 grid(n, (G.nCells + FAST_CPW - 1) / FAST_CPW, 1), block(64, 1, 1);
+            // the kernel is instantiated for every ROI pitch a cell of 30 .. 59 pixels can have
+            auto kf = k_fast<0>;
+            switch (G.roiPitch) {
+                case 40: kf = k_fast<40>; break;
+                case 44: kf = k_fast<44>; break;
+                case 48: kf = k_fast<48>; break;
+                case 52: kf = k_fast<52>; break;
+                case 56: kf = k_fast<56>; break;
+                case 60: kf = k_fast<60>; break;
+                case 64: kf = k_fast<64>; break;
+                case 68: kf = k_fast<68>; break;
+                default: break;
+            }
+            if (h->fastGenericPitch) kf = k_fast<0>;
+            hipLaunchKernelGGL(kf, grid, block, G.ldsBytes + ldsPad, st, g, img0, aligned0, (const u8*)h->dPyr,
+                               (const FastCell*)h->dCells, h->dCellCount, h->dSlots, std::min(std::max(h->cfg.ini_th_fast, 0), 255),
+                               std::min(std::max(h->cfg.min_th_fast, 0), 255), G);
         }
     }
     if (lateFork) {

@@ -9,9 +9,14 @@ FILES = ("slam_amd/csrc/orbx_extract.hip", "slam_amd/csrc/orbx_match.hip", "slam
 
 
 def kernel_source_hash():
+    """Lines are hashed without their indentation, trailing blanks and empty lines, so that a change
+    of layout alone does not make the committed counter summaries look stale."""
     h = hashlib.sha256()
     for f in FILES:
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+        for line in open(os.path.join(ROOT, f), "rb").read().split(b"\n"):
+            line = line.strip()
+            if line:
+                h.update(line + b"\n")
     return h.hexdigest()[:16]
 
 
