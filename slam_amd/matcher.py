@@ -13,6 +13,17 @@ from . import _lib
 from ._lib import KP_DTYPE, MEM_HOST, MFrame, ProjPolicy, ProjQueries, check
 
 
+
+def _nmatches(arr):
+    """The nmatches field of every record of a ctypes job array, read in one strided view instead of
+    one attribute access per record (the tables of the batched searches hold a thousand records)."""
+    if len(arr) == 0:
+        return []
+    rec = type(arr[0])
+    raw = np.frombuffer(arr, dtype=np.uint8).reshape(len(arr), C.sizeof(rec))
+    off = rec.nmatches.offset
+    return raw[:, off:off + 4].copy().view(np.int32).reshape(-1).tolist()
+
 class FrameView:
     """The matcher's view of a Frame: undistorted keypoints, descriptors, image bounds."""
 
@@ -118,7 +129,7 @@ class ORBmatcher:
             arr[i].matches12 = p["matches12"].data_ptr()
         check(self._lib.orbm_search_for_initialization_batch(self._m, arr, len(arr), int(windowSize), float(self.mfNNratio),
                                                              int(self.mbCheckOrientation)))
-        return [arr[i].nmatches for i in range(len(arr))]
+        return _nmatches(arr)
 
     # ---- projected searches
     def _claims(self, n, claimed, claimed_obs):
@@ -266,7 +277,7 @@ class ORBmatcher:
         sf = np.ascontiguousarray(scale_factors, np.float32)
         check(self._lib.orbm_search_by_projection_batch(self._m, arr, len(arr), sf.ctypes.data, len(sf), float(bf),
                                                         float(th), int(self.mbCheckOrientation)))
-        return [arr[i].nmatches for i in range(len(arr))]
+        return _nmatches(arr)
 
     def SearchProjectedBatch(self, jobs, policy, window_hint=0.0):
         """orbm_search_projected for many independent (frame, projected point set) jobs in one call: the batched
@@ -289,7 +300,7 @@ class ORBmatcher:
             arr[i].query_best = ptr(p.get("query_best"))
         pol = _lib.ProjPolicy(int(policy[0]), int(policy[1]), int(policy[2]), float(policy[3]), int(policy[4]))
         check(self._lib.orbm_search_projected_batch(self._m, arr, len(arr), C.byref(pol), float(window_hint)))
-        return [arr[i].nmatches for i in range(len(arr))]
+        return _nmatches(arr)
 
     # ---- vocabulary-guided searches
     @staticmethod
@@ -328,7 +339,7 @@ class ORBmatcher:
             arr[i].match21 = p["match21"].data_ptr()
         check(self._lib.orbm_search_by_bow_batch(self._m, arr, len(arr), self.TH_LOW - 1 if keyframe_pair else self.TH_LOW,
                                                  float(self.mfNNratio), int(self.mbCheckOrientation)))
-        return [arr[i].nmatches for i in range(len(arr))]
+        return _nmatches(arr)
 
     def SearchByBoW(self, F1, fv1, valid1, F2, fv2, valid2=None, keyframe_pair=False):
         """ORBmatcher::SearchByBoW.  keyframe_pair=False: (KeyFrame*, Frame&) overload (reference
