@@ -1386,29 +1386,27 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
 }
 
 // ------------------------------------------------------------------ quadtree
-__device__ __forceinline__ int wave_incl_scan(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
+// Inclusive prefix sum over the wave (all lanes active): the DPP form, six dependent additions, where
+// the shuffle form paid a round trip through the LDS crossbar per step.
+__device__ __forceinline__ int wave_incl_scan(int v) { return wave_incl_scan_dpp(v); }
 
 // Threads per quadtree workgroup.  Measured on MI355X at 640x480 / 1000 features: 256 is best (128 and 512
 // slower, a single wave much slower); levels with thousands of nodes and 10^5 candidates want more.
 
 // Exclusive scan over the QT_THREADS threads of the block; *total = block sum.
+// wsum: 2 x 16 partial sums, the two halves used by alternate calls (every thread of the block makes the
+// same sequence of calls): the readers of a half have all passed the barrier of the next call before
+// the call after that writes it again, so one barrier per scan is enough.
 template <int QT_THREADS>
-__device__ __forceinline__ int block_excl_scan(int v, int* total, int* wsum) {
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* wsumBoth, int& phase) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int inc = wave_incl_scan(v);
     if (QT_THREADS == 64) {
         *total = __builtin_amdgcn_readlane(inc, 63);
         return inc - v;
     }
-    __syncthreads();
+    int* wsum = wsumBoth + 16 * phase;
+    phase ^= 1;
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
     int base = 0, tot = 0;
@@ -1424,7 +1422,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* wsum) {
 
 struct QtShared {
     int n, L, prevL, tnew, ncut, nproc, toExpand, done, careful, C;
-    int wsum[16];
+    int wsum[32];
 };
 
 __device__ __forceinline__ int child_quadrant(u32 key, short4 b) {
@@ -1446,6 +1444,20 @@ __device__ __forceinline__ short4 child_box(short4 b, int q) {
     return r;
 }
 
+#ifdef ORBX_QT_DIAG
+// Diagnostic build: thread 0 of the level-0 workgroup of frame 0 prints the cycles between phase marks.
+#define QT_MARK(name)                                                                         \
+    do {                                                                                      \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                         \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                     \
+            printf("qt %s %u L %d nkeys %d\n", name, (unsigned)(now_ - qtLast), S.L, nkeys);  \
+            qtLast = __builtin_amdgcn_s_memtime();                                            \
+        }                                                                                     \
+    } while (0)
+#else
+#define QT_MARK(name)
+#endif
+
 // DistributeOctTree for one (frame, level).  The list of nodes is kept as
 // arrays indexed by list position; every pass rebuilds the list with prefix
 // sums so that positions, creation order and the stop rule equal those of the
@@ -1466,6 +1478,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     const int l = blockIdx.y, f = blockIdx.x;
     const LevelGeom& LG = g.lv[l];
     const int tid = threadIdx.x;
+    int scanPhase = 0;  // which half of S.wsum the next block scan uses
+#ifdef ORBX_QT_DIAG
+    unsigned long long qtLast = __builtin_amdgcn_s_memtime();
+#endif
     const int lcap = LG.lcap;
     const int N = LG.quota;
     int* selCnt = selCount + (i64)f * ORBX_MAX_LEVELS + l;
@@ -1502,11 +1518,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         const int c = base + tid;
         const int cN = c < LG.nCells ? (int)cc[c] : 0;
         int tot;
-        const int off = block_excl_scan<QT_THREADS>(cN, &tot, S.wsum);
+        const int off = block_excl_scan<QT_THREADS>(cN, &tot, S.wsum, scanPhase);
         for (int k = 0; k < cN; k++) kp[nkeys + off + k] = sl[(i64)c * LG.cellCap + k];
         nkeys += tot;
     }
     __syncthreads();
+    QT_MARK("gather");
     if (nkeys == 0) {
         if (tid == 0) *selCnt = 0;
         return;
@@ -1547,10 +1564,20 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         S.done = 0;
     }
     __syncthreads();
-    for (int k = tid; k < nkeys; k += QT_THREADS) kn[k] = moved[kn[k]];
+    // Every pass needs, per node that can be split, the number of its keys in each quadrant.  The counts
+    // of a pass are gathered while the keys are moved to the nodes of that pass (here for the roots,
+    // at the end of a pass for the next one), so a pass sweeps the keys once, not twice.
+    for (int i = tid; i < S.L * 4; i += QT_THREADS) childCnt[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < nkeys; k += QT_THREADS) {
+        const int nd = moved[kn[k]];
+        kn[k] = (u16)nd;
+        if (cnt[1][nd] > 1) atomicAdd(&childCnt[nd * 4 + child_quadrant(kp[k], box[1][nd])], 1u);
+    }
     int cur = 1;  // buffer holding the current list
     u32 nextSeq = (u32)nIni;
     __syncthreads();
+    QT_MARK("roots");
 
     // ---- subdivision passes (reference :596-741)
     for (int iter = 0; iter < 64; iter++) {
@@ -1560,25 +1587,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         const u32* ccnt = cnt[cur];
         const u32* cseq = seq[cur];
         const int nxt = cur ^ 1;
-        for (int i = tid; i < L * 4; i += QT_THREADS) childCnt[i] = 0;
-        __syncthreads();
-        // four keys per trip: the loads of a trip are issued together, so a thread waits for
-        // memory once per four keys
-        for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
-            int nd[4];
-            u32 key[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int k = min(k0 + j * QT_THREADS, nkeys - 1);
-                nd[j] = kn[k];
-                key[j] = kp[k];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (k0 + j * QT_THREADS < nkeys && ccnt[nd[j]] > 1)
-                    atomicAdd(&childCnt[nd[j] * 4 + child_quadrant(key[j], cb[nd[j]])], 1u);
-        }
-        __syncthreads();
+        // (childCnt holds the quadrant counts of this pass's nodes: gathered when the keys were moved here)
         // processing order of expandable nodes
         int C = 0;
         if (!careful) {
@@ -1586,7 +1595,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 const int i = base + tid;
                 const int e = (i < L && ccnt[i] > 1) ? 1 : 0;
                 int tot;
-                const int off = block_excl_scan<QT_THREADS>(e, &tot, S.wsum);
+                const int off = block_excl_scan<QT_THREADS>(e, &tot, S.wsum, scanPhase);
                 if (i < L) rankOf[i] = e ? (u16)(C + off) : (u16)0xFFFF;
                 C += tot;
             }
@@ -1601,6 +1610,35 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
             u64* srt = (u64*)gpre;
             int P = 2;
             while (P < L) P <<= 1;
+            if (P <= QT_THREADS) {
+                // One element per thread, kept in a register: a compare-exchange whose partner sits in the
+                // same wave (distance below 64) is a shuffle, only the longer distances go through LDS
+                // and a barrier (3 of the 36 steps for 256 elements).  Element i of a pair (i, i ^ j) keeps
+                // the larger value when it is the lower index of a descending block or the upper index of
+                // an ascending one.
+                u64 val = (tid < L && ccnt[tid] > 1) ? (((u64)ccnt[tid] << 32) | (u64)(0xFFFFFFFFu - (u32)tid)) : 0ull;
+                for (int k = 2; k <= P; k <<= 1) {
+                    const bool desc = (tid & k) == 0;   // descending blocks first: the whole ends descending
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        u64 other;
+                        if (j >= 64) {                   // uniform over the block
+                            __syncthreads();             // the previous exchange has been read
+                            if (tid < P) srt[tid] = val;
+                            __syncthreads();
+                            other = tid < P ? srt[tid ^ j] : 0ull;
+                        } else {
+                            other = __shfl_xor(val, j);
+                        }
+                        const bool lower = (tid & j) == 0;
+                        const u64 hi = val > other ? val : other, lo = val > other ? other : val;
+                        val = (desc == lower) ? hi : lo;
+                    }
+                }
+                __syncthreads();  // the last exchange buffer has been read: rankOf may overlap its padding
+                for (int i = tid; i < L; i += QT_THREADS) rankOf[i] = 0xFFFF;
+                __syncthreads();
+                if (tid < P && val != 0ull) rankOf[0xFFFFFFFFu - (u32)val] = (u16)tid;
+            } else {
             for (int i = tid; i < P; i += QT_THREADS)
                 srt[i] = (i < L && ccnt[i] > 1) ? (((u64)ccnt[i] << 32) | (u64)(0xFFFFFFFFu - (u32)i)) : 0ull;
             __syncthreads();
@@ -1626,15 +1664,17 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 const u64 key = srt[r];
                 if (key != 0ull) rankOf[0xFFFFFFFFu - (u32)key] = (u16)r;
             }
+            }
             for (int base = 0; base < L; base += QT_THREADS) {
                 const int i = base + tid;
                 const int e = (i < L && ccnt[i] > 1) ? 1 : 0;
                 int tot;
-                block_excl_scan<QT_THREADS>(e, &tot, S.wsum);
+                block_excl_scan<QT_THREADS>(e, &tot, S.wsum, scanPhase);
                 C += tot;
             }
         }
         __syncthreads();
+        QT_MARK(careful ? "sort+rank" : "rank");
         for (int i = tid; i < L; i += QT_THREADS) {
             const u16 r = rankOf[i];
             int m = 0;
@@ -1652,7 +1692,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
             const int j = base + tid;
             const int m = j < C ? (int)mOf[nodeOfRank[j]] : 0;
             int tot;
-            const int off = block_excl_scan<QT_THREADS>(m, &tot, S.wsum);
+            const int off = block_excl_scan<QT_THREADS>(m, &tot, S.wsum, scanPhase);
             int lt = 0;
             if (j < C) {
                 gpre[j] = (u32)(run + off);
@@ -1660,13 +1700,14 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 lt = (L + (run + off + m) - (j + 1)) < N ? 1 : 0;
             }
             int tl;
-            block_excl_scan<QT_THREADS>(lt, &tl, S.wsum);
+            block_excl_scan<QT_THREADS>(lt, &tl, S.wsum, scanPhase);
             below += tl;
             run += tot;
         }
         int nproc = C;
         if (careful) nproc = min(C, below + 1);
         __syncthreads();
+        QT_MARK("cutscan");
         int tnew = 0;
         if (nproc > 0) {
             const int last = nodeOfRank[nproc - 1];
@@ -1678,7 +1719,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
             const int i = base + tid;
             const int s = (i < L && (rankOf[i] == 0xFFFF || rankOf[i] >= nproc)) ? 1 : 0;
             int tot;
-            const int off = block_excl_scan<QT_THREADS>(s, &tot, S.wsum);
+            const int off = block_excl_scan<QT_THREADS>(s, &tot, S.wsum, scanPhase);
             if (s) {
                 const int np = tnew + stay + off;
                 moved[i] = (u16)np;
@@ -1714,10 +1755,20 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         }
         {
             int tot;
-            block_excl_scan<QT_THREADS>(expand, &tot, S.wsum);
+            block_excl_scan<QT_THREADS>(expand, &tot, S.wsum, scanPhase);
             expand = tot;
         }
+        QT_MARK("stay+child");
+        // (the barrier inside the scan: every thread is through with this pass's quadrant counts)
+        const int newL = tnew + stay;
+        const int nextL = min(newL, lcap);
+        for (int i = tid; i < nextL * 4; i += QT_THREADS) childCnt[i] = 0;
         __syncthreads();
+        // keys move to their nodes of the next list and are counted into the quadrants of those nodes;
+        // four keys per trip: the loads of a trip are issued together, so a thread waits for memory once
+        // per four keys
+        const short4* nb = box[nxt];
+        const u32* ncnt = cnt[nxt];
         for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
             int nd[4];
             u32 key[4];
@@ -1732,16 +1783,19 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 const int k = k0 + j * QT_THREADS;
                 if (k < nkeys) {
                     const u16 r = rankOf[nd[j]];
+                    int to;
                     if (r != 0xFFFF && r < nproc)
-                        kn[k] = newId[nd[j] * 4 + child_quadrant(key[j], cb[nd[j]])];
+                        to = newId[nd[j] * 4 + child_quadrant(key[j], cb[nd[j]])];
                     else
-                        kn[k] = moved[nd[j]];
+                        to = moved[nd[j]];
+                    kn[k] = (u16)to;
+                    if (to < nextL && ncnt[to] > 1) atomicAdd(&childCnt[to * 4 + child_quadrant(key[j], nb[to])], 1u);
                 }
             }
         }
         nextSeq += (u32)tnew;
-        const int newL = tnew + stay;
         __syncthreads();
+        QT_MARK("sweep");
         if (tid == 0) {
             if (newL > lcap) {
                 *errFlag = 1;
@@ -1784,6 +1838,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         const u32 key = kp[k];
         selOut[i] = ORBX_PACK(ORBX_PX(key) + MIN_BORDER, ORBX_PY(key) + MIN_BORDER, ORBX_PR(key));
     }
+    QT_MARK("best");
     if (tid == 0) *selCnt = L;
 }
 
