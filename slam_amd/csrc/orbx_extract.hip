@@ -1535,10 +1535,22 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     const int ySpan = LG.h - 2 * MIN_BORDER;
     for (int i = tid; i < lcap; i += QT_THREADS) cnt[0][i] = 0;
     __syncthreads();
-    for (int k = tid; k < nkeys; k += QT_THREADS) {
-        const int r = (int)((float)ORBX_PX(kp[k]) / hX);
-        kn[k] = (u16)r;
-        atomicAdd(&cnt[0][r], 1u);
+    // With one or two initial nodes (the usual aspect ratios) every key of a wave would hit the same one
+    // or two LDS counters: the wave counts its keys per node with ballots and adds once per node.
+    const bool fewRoots = nIni <= 2;
+    for (int k0 = 0; k0 < nkeys; k0 += QT_THREADS) {
+        const int k = k0 + tid;
+        const int r = k < nkeys ? (int)((float)ORBX_PX(kp[k]) / hX) : -1;
+        if (k < nkeys) kn[k] = (u16)r;
+        if (fewRoots) {
+            const u64 m0 = __ballot(r == 0), m1 = __ballot(r == 1);
+            if ((tid & 63) == 0) {
+                if (m0) atomicAdd(&cnt[0][0], (u32)__popcll(m0));
+                if (m1) atomicAdd(&cnt[0][1], (u32)__popcll(m1));
+            }
+        } else if (k < nkeys) {
+            atomicAdd(&cnt[0][r], 1u);
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -1569,10 +1581,23 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     // at the end of a pass for the next one), so a pass sweeps the keys once, not twice.
     for (int i = tid; i < S.L * 4; i += QT_THREADS) childCnt[i] = 0;
     __syncthreads();
-    for (int k = tid; k < nkeys; k += QT_THREADS) {
-        const int nd = moved[kn[k]];
-        kn[k] = (u16)nd;
-        if (cnt[1][nd] > 1) atomicAdd(&childCnt[nd * 4 + child_quadrant(kp[k], box[1][nd])], 1u);
+    for (int k0 = 0; k0 < nkeys; k0 += QT_THREADS) {
+        const int k = k0 + tid;
+        int code = -1;  // node * 4 + quadrant of a key that is counted
+        if (k < nkeys) {
+            const int nd = moved[kn[k]];
+            kn[k] = (u16)nd;
+            if (cnt[1][nd] > 1) code = nd * 4 + child_quadrant(kp[k], box[1][nd]);
+        }
+        if (fewRoots) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const u64 m = __ballot(code == c);
+                if (m && (tid & 63) == 0) atomicAdd(&childCnt[c], (u32)__popcll(m));
+            }
+        } else if (code >= 0) {
+            atomicAdd(&childCnt[code], 1u);
+        }
     }
     int cur = 1;  // buffer holding the current list
     u32 nextSeq = (u32)nIni;
