@@ -60,6 +60,200 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """(cores this process may run on, threads used by the CPU legs).  The legs use every core of the
+    process's affinity mask, bounded by ORBX_BENCH_CPU_THREADS (default 256) so that a very wide host does
+    not spawn thousands of threads for a bounded sample."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 1
+    return avail, max(1, min(avail, int(os.environ.get("ORBX_BENCH_CPU_THREADS", "256"))))
+
+
+def kitti_pipeline(dev, stream, barrier, synth, ORBextractor, ORBmatcher, npairs=1024, chunk=256, cpu=True):
+    """BASELINE config 3 as a device-resident pipeline: 1241x376 stereo frames, 2000 features per image.
+    Per frame: extraction of both images, ComputeStereoMatches; per consecutive frame pair: frame-to-frame
+    SearchByProjection (th 7, bMono false) with the mvuRight gate fed by the stereo step.  The frames are
+    cut two per synthetic scene (the second displaced by (2, -1) pixels), so npairs stereo frames give
+    npairs projection searches (each scene's pair in both orders)."""
+    import torch
+    w2, h2, nf2 = 1241, 376, 2000
+    FX, CX, CY, MBF = 718.856, 607.1928, 185.2157, 386.1448
+    MB = MBF / FX
+    out = {}
+    el = ORBextractor(nf2, 1.2, NLEVELS, 20, 7, max_width=w2, max_height=h2, max_batch=chunk, device=dev.index)
+    er = ORBextractor(nf2, 1.2, NLEVELS, 20, 7, max_width=w2, max_height=h2, max_batch=chunk, device=dev.index)
+    mm = ORBmatcher(0.9, True, device=dev.index)
+    for o in (el, er, mm):
+        o.set_stream(stream.cuda_stream)
+    cap2 = el.max_keypoints()
+    pitch = (w2 + 3) // 4 * 4
+    margin, vm, dt, db = 80, 16, 6, 13
+    bl = torch.zeros((npairs, h2, pitch), dtype=torch.uint8, device=dev)
+    br = torch.zeros((npairs, h2, pitch), dtype=torch.uint8, device=dev)
+    for s0 in range(0, npairs // 2, 8):
+        n = min(8, npairs // 2 - s0)
+        scene = synth.synth_batch_torch(n, w2 + 2 * margin, h2 + 2 * vm, 0x5EED7001 + s0, device=dev)
+        for k, (dx, dy) in enumerate(((0, 0), (2, -1))):
+            x0, y0 = margin + dx, vm + dy
+            split = vm + h2 // 2 - y0
+            f = slice(2 * s0 + k, 2 * (s0 + n) + k, 2)
+            bl[f, :, :w2] = scene[:, y0:y0 + h2, x0:x0 + w2]
+            br[f, :split, :w2] = scene[:, y0:y0 + split, x0 + dt:x0 + dt + w2]
+            br[f, split:, :w2] = scene[:, y0 + split:y0 + h2, x0 + db:x0 + db + w2]
+        del scene
+    kL = torch.zeros(npairs * cap2 * 28, dtype=torch.uint8, device=dev)
+    dL = torch.zeros(npairs * cap2 * 32, dtype=torch.uint8, device=dev)
+    nL = torch.zeros(npairs, dtype=torch.int32, device=dev)
+    kR, dR, nR = torch.zeros_like(kL), torch.zeros_like(dL), torch.zeros_like(nL)
+    uR = torch.full((npairs, cap2), -1.0, dtype=torch.float32, device=dev)
+    dp = torch.full((npairs, cap2), -1.0, dtype=torch.float32, device=dev)
+    kLv, dLv, kRv, dRv = kL.view(npairs, cap2, 28), dL.view(npairs, cap2, 32), kR.view(npairs, cap2, 28), dR.view(npairs, cap2, 32)
+
+    def extract_chunk(c0, c1):
+        el.extract_batch_device(bl[c0:c1, :, :w2], kLv[c0:c1].reshape(-1), dLv[c0:c1].reshape(-1), nL[c0:c1], cap2)
+        er.extract_batch_device(br[c0:c1, :, :w2], kRv[c0:c1].reshape(-1), dRv[c0:c1].reshape(-1), nR[c0:c1], cap2)
+
+    # warm-up pass: also builds the stereo job table of every chunk (the pyramids of a chunk are resident
+    # after its extraction; later passes reuse the same buffers, so the tables stay valid)
+    tables = []
+    for c0 in range(0, npairs, chunk):
+        c1 = min(c0 + chunk, npairs)
+        extract_chunk(c0, c1)
+        el.synchronize()
+        er.synchronize()
+        nl, nr = nL[c0:c1].cpu().numpy(), nR[c0:c1].cpu().numpy()
+        jobs = [dict(kps_left=kLv[c0 + i, :int(nl[i])], desc_left=dLv[c0 + i, :int(nl[i])],
+                     kps_right=kRv[c0 + i, :int(nr[i])], desc_right=dRv[c0 + i, :int(nr[i])],
+                     pyr_left=mm.pyramid_of(el, i), pyr_right=mm.pyramid_of(er, i),
+                     u_right=uR[c0 + i, :int(nl[i])], depth=dp[c0 + i, :int(nl[i])]) for i in range(c1 - c0)]
+        tables.append(mm.stereo_job_table(jobs))
+        mm.ComputeStereoMatchesBatch(tables[-1], el, MB, MBF)
+    nl_all = nL.cpu().numpy()
+    # projection inputs on the device from the stereo depth: the last frame's stereo points moved by a small
+    # translation (float32 torch arithmetic; an input of the search, the same for the CPU leg)
+    kf = kLv.contiguous().view(torch.float32).view(npairs, cap2, 7)
+    z = torch.where(dp > 0, dp, torch.ones_like(dp))
+    X = (kf[:, :, 0] - CX) * z / FX
+    Y = (kf[:, :, 1] - CY) * z / FX
+    sign = torch.ones((npairs, 1), device=dev)
+    sign[1::2] = -1.0  # frame 2k -> 2k+1 sees the scene move by (-2, +1) pixels' worth; 2k+1 -> 2k the opposite
+    tz = 0.65
+    zc = z + sign * tz
+    uu = (FX * (X - sign * 0.12) / zc + CX).contiguous()
+    vv = (FX * (Y + sign * 0.06) / zc + CY).contiguous()
+    invz = (1.0 / zc).contiguous()
+    valid = (dp > 0).to(torch.uint8).contiguous()
+    ones8 = torch.ones((npairs, cap2), dtype=torch.uint8, device=dev)
+    claimed = torch.full((npairs, cap2), -1, dtype=torch.int32, device=dev)
+    cobs = torch.zeros((npairs, cap2), dtype=torch.uint8, device=dev)
+    pairs = []
+    for i in range(npairs):
+        j = i ^ 1  # the other frame of the scene is the current frame
+        n, nc = int(nl_all[i]), int(nl_all[j])
+        pairs.append(dict(cur_kps=kLv[j, :nc], cur_desc=dLv[j, :nc], last_kps=kLv[i, :n], last_desc=dLv[i, :n],
+                          valid=valid[i, :n], u=uu[i, :n], v=vv[i, :n], invz=invz[i, :n], has_obs=ones8[i, :n],
+                          cur_u_right=uR[j, :nc], claimed=claimed[j, :nc], claimed_obs=cobs[j, :nc],
+                          direction=2 if i % 2 == 0 else 1, bounds=(0.0, 0.0, float(w2), float(h2))))
+    sfac = el.GetScaleFactors()
+    ptable = mm.projection_pair_table(pairs)
+    counts = mm.SearchByProjectionBatch(ptable, sfac, MBF, 7.0)
+    barrier()
+    # ---- timed: the whole pipeline, with the stereo and projection calls timed on their own inside it
+    reps = 2
+    t_st = t_pr = 0.0
+    n_st = 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for ci, c0 in enumerate(range(0, npairs, chunk)):
+            c1 = min(c0 + chunk, npairs)
+            extract_chunk(c0, c1)
+            el.synchronize()
+            er.synchronize()
+            t1 = time.perf_counter()
+            cnt = mm.ComputeStereoMatchesBatch(tables[ci], el, MB, MBF)
+            t_st += time.perf_counter() - t1
+            n_st += sum(cnt)
+        claimed.fill_(-1)
+        cobs.zero_()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        counts = mm.SearchByProjectionBatch(ptable, sfac, MBF, 7.0)
+        torch.cuda.synchronize()
+        t_pr += time.perf_counter() - t1
+    barrier()
+    t_all = time.perf_counter() - t0
+    # ---- extraction alone, both images of every frame, default schedule (all chunks in one call per side)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        el.extract_batch_device(bl[:, :, :w2], kL, dL, nL, cap2)
+        er.extract_batch_device(br[:, :, :w2], kR, dR, nR, cap2)
+    barrier()
+    t_ex = time.perf_counter() - t1
+    nq = float(valid.sum().item())
+    out = {"stereo_frames": npairs, "frames_per_pass": chunk, "features": nf2,
+           "extraction_frames_per_s": round(2 * npairs * reps / t_ex, 1),
+           "stereo_points_per_s": round(float(nl_all.sum()) * reps / t_st, 1),
+           "stereo_frames_per_s": round(npairs * reps / t_st, 1),
+           "stereo_points_found_per_frame": round(n_st / (reps * npairs), 1),
+           "projection_queries_per_s": round(nq * reps / t_pr, 1),
+           "projection_pairs_per_s": round(npairs * reps / t_pr, 1),
+           "projection_matches_per_pair": round(float(np.mean(counts)), 1),
+           "pipeline_stereo_frames_per_s": round(npairs * reps / t_all, 1),
+           "mean_keypoints_left": round(float(nl_all.mean()), 1), "th": 7.0, "bMono": False,
+           "note": "1241x376 rows padded to 1244 bytes; extraction of both images + orbm_compute_stereo_matches_batch "
+                   "per pass of frames, orbm_search_by_projection_batch over all frame pairs (mvuRight gate fed by the "
+                   "stereo output), everything resident in HBM; the stereo and projection rates are host wall time of "
+                   "their synchronous calls inside the pipeline loop"}
+    if cpu:
+        # CPU leg on a bounded sample: the oracle's ComputeStereoMatches and SearchByProjection over the first
+        # frames, single thread (the reference runs them on the tracking thread), with parity of that sample
+        from oracle import pyoracle as O
+        from slam_amd._lib import KP_DTYPE
+        S = 8
+        p = O.params(nfeatures=nf2)
+        imgs_l = bl[:S, :, :w2].cpu().numpy()
+        imgs_r = br[:S, :, :w2].cpu().numpy()
+        n_r = nR.cpu().numpy()
+        bad = 0
+        t_cs = t_cp = 0.0
+        q_cpu = 0
+        fr = []
+        for i in range(S):
+            kl = kLv[i, :int(nl_all[i])].cpu().numpy().view(KP_DTYPE).reshape(-1)
+            dl = dLv[i, :int(nl_all[i])].cpu().numpy()
+            kr = kRv[i, :int(n_r[i])].cpu().numpy().view(KP_DTYPE).reshape(-1)
+            dr = dRv[i, :int(n_r[i])].cpu().numpy()
+            t1 = time.perf_counter()
+            on, our, odp = O.compute_stereo_matches(p, imgs_l[i], imgs_r[i], kl, dl, kr, dr, MB, MBF)
+            t_cs += time.perf_counter() - t1
+            bad += int((our.view(np.uint32) != uR[i, :len(kl)].cpu().numpy().view(np.uint32)).sum())
+            fr.append((kl, dl, our))
+        cl_dev = claimed.cpu().numpy()
+        for i in range(S):
+            j = i ^ 1
+            (ka, da, _), (kb, dbb, urb) = fr[i], fr[j]
+            oc = O.FrameData(kb, dbb, (0.0, 0.0, float(w2), float(h2)), sfac)
+            ol = O.FrameData(ka, da, (0.0, 0.0, float(w2), float(h2)), sfac)
+            n = len(ka)
+            a = [x[i, :n].cpu().numpy() for x in (valid, uu, vv, invz, ones8)]
+            t1 = time.perf_counter()
+            rn, rcl, rco = O.search_by_projection_frames(oc, ol, a[0], a[1], a[2], a[3], a[4], urb, MBF, 7.0,
+                                                         2 if i % 2 == 0 else 1, True)
+            t_cp += time.perf_counter() - t1
+            q_cpu += int(a[0].sum())
+            bad += int((rcl != cl_dev[j, :len(kb)]).sum())
+        out["cpu_baseline"] = {"kind": "port", "cores": 1, "sample": "first %d stereo frames, oracle, single thread" % S,
+                               "stereo_points_per_s": round(sum(len(f[0]) for f in fr) / t_cs, 1),
+                               "projection_queries_per_s": round(q_cpu / t_cp, 1), "unit": "points/s, queries/s",
+                               "mismatches_vs_device": bad}
+    mm.close()
+    el.close()
+    er.close()
+    return out
+
+
 def main():
     if os.environ.get("ORBX_BENCH_WATCHDOG"):
         # diagnostic: after that many seconds every thread's Python stack goes to stderr (the run continues)
@@ -251,7 +445,7 @@ def main():
         from oracle import pyoracle as O
         S = min(args.cpu_frames, B)
         host = frames[:S].cpu().numpy()
-        threads = max(1, min(16, os.cpu_count() or 1))
+        avail, threads = host_cores()
         p = O.params(NFEAT, 1.2, NLEVELS, 20, 7)
         t1 = time.perf_counter()
         rk, rd, rn = O.extract_batch(p, host, cap=cap, threads=threads)
@@ -261,9 +455,16 @@ def main():
         O.extract_batch(p, host[:s1], cap=cap, threads=1)
         cpu_1t = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(S / cpu_mt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+                               "cores_available": avail, "threads_used": threads,
+                               "hardware_concurrency": os.cpu_count(),
                                "sample": "first %d of the benchmark's frames, oracle (C++ restatement of the "
-                                         "reference path, not OpenCV), frame-parallel std::thread" % S,
+                                         "reference path, not OpenCV), frame-parallel std::thread on every core of "
+                                         "the process's affinity mask" % S,
                                "single_thread_frames_per_s": round(s1 / cpu_1t, 2), "single_thread_sample_frames": s1}
+        if threads != 16 and avail >= 16:
+            t1 = time.perf_counter()
+            O.extract_batch(p, host[:min(S, 512)], cap=cap, threads=16)
+            out["cpu_baseline"]["frames_per_s_16_threads"] = round(min(S, 512) / (time.perf_counter() - t1), 2)
         s2 = min(64, S)
         st_cpu = O.extract_stages(p, host[:s2])
         tot_cpu = sum(st_cpu.values()) or 1.0
@@ -300,12 +501,14 @@ def main():
     if world > 1 and not args.no_hamming:
         # The headline line is out.  The leg below has a collective exchange: should it ever stall (a rank
         # lost, a fabric problem), every rank ends its process after ORBX_BENCH_LEG_TIMEOUT seconds
-        # (default 300) with status 0 instead of holding the job until something kills it.
+        # (default 300) with status 3 (a failure: the headline stands, the leg is reported as timed out)
+        # instead of holding the job until something kills it.
         import threading
 
         def _give_up():
+            print("hamming: " + json.dumps({"error": "timeout"}), file=sys.stderr, flush=True)
             print("bench: the multi-rank Hamming leg exceeded its time limit; ending without it", file=sys.stderr, flush=True)
-            os._exit(0)
+            os._exit(3)
 
         guard = threading.Timer(float(os.environ.get("ORBX_BENCH_LEG_TIMEOUT", "300")), _give_up)
         guard.daemon = True
@@ -396,6 +599,32 @@ def main():
                               "vector_alu_issue_bound_pairs_per_s_per_gpu": round(issue_bound, 1),
                               "exchange": ("all-gather queries + all-to-all partials (RCCL)" if torch.distributed.get_backend() == "nccl"
                                            else "all-gather queries + all-gather partials (gloo rehearsal)") if world > 1 else "none"}
+            if rank == 0 and world == 1 and not args.no_cpu:
+                # CPU side of the same metric: the oracle's serial scan (the reference's descriptor loop and
+                # DescriptorDistance, src/ORBmatcher.cc:255-288, :1905-1921) over a slice of the queries against
+                # ALL train rows, query-parallel on the host cores, extrapolated linearly to the full query set
+                from oracle import pyoracle as O
+                avail, threads = host_cores()
+                nqs = min(1 << 12, NQ)
+                t1 = time.perf_counter()
+                ci, cd, cs = O.knn2(q_h[:nqs], t_h, threads=threads)
+                dt_c = time.perf_counter() - t1
+                if dt_c < 4.0 and NQ >= (1 << 14):
+                    nqs = 1 << 14
+                    t1 = time.perf_counter()
+                    ci, cd, cs = O.knn2(q_h[:nqs], t_h, threads=threads)
+                    dt_c = time.perf_counter() - t1
+                r = search(q_l, t_l)
+                torch.cuda.synchronize()
+                same = (np.array_equal(r[0][:nqs].cpu().numpy(), ci) and np.array_equal(r[1][:nqs].cpu().numpy(), cd)
+                        and np.array_equal(r[2][:nqs].cpu().numpy(), cs))
+                out["hamming"]["cpu_baseline"] = {
+                    "value": round(float(nqs) * NT / dt_c, 1), "unit": "pairs/s", "cores": threads, "cores_available": avail,
+                    "kind": "port", "sample": "%d x %d slice of the same data (first queries, all train rows), oracle "
+                                              "serial scan with the reference's SWAR popcount, query-parallel; "
+                                              "the full job is this rate extrapolated linearly" % (nqs, NT),
+                    "extrapolated_seconds_full_job": round(float(NQ) * NT / (float(nqs) * NT / dt_c), 1),
+                    "slice_equals_device_result": bool(same)}
             m.close()
 
         except Exception as e:  # noqa: BLE001
@@ -445,6 +674,30 @@ def main():
                                         "queries_per_pair": round(float(nk.mean()), 1), "th": 7.0,
                                         "matches_per_pair": round(float(np.mean(counts)), 1),
                                         "note": "orbm_search_by_projection_batch, device-resident"}
+            if not args.no_cpu:
+                # CPU side: the oracle's SearchByProjection (src/ORBmatcher.cc:1533-1678) over the first pairs of
+                # the same table, single thread (the reference runs it on the tracking thread)
+                from oracle import pyoracle as O
+                SP = min(32, NP)
+                cl_dev = claimed[:SP].cpu().numpy()
+                kh = kview[:SP].cpu().numpy().view(KP_DTYPE).reshape(SP, cap)
+                dh = dview[:SP].cpu().numpy()
+                uh, vh = uu[:SP].cpu().numpy(), vv[:SP].cpu().numpy()
+                t_c, q_c, bad = 0.0, 0, 0
+                for i in range(SP):
+                    n = int(nk[i])
+                    fd = O.FrameData(kh[i, :n], dh[i, :n], (0.0, 0.0, float(W), float(H)), sfac)
+                    t1 = time.perf_counter()
+                    rn, rcl, rco = O.search_by_projection_frames(fd, fd, np.ones(n, np.uint8), uh[i, :n], vh[i, :n],
+                                                                 np.full(n, 0.5, np.float32), np.ones(n, np.uint8),
+                                                                 np.full(n, -1.0, np.float32), 40.0, 7.0, 0, True)
+                    t_c += time.perf_counter() - t1
+                    q_c += n
+                    bad += int((rcl != cl_dev[i, :n]).sum())
+                out["projection_search"]["cpu_baseline"] = {
+                    "value": round(q_c / t_c, 1), "unit": "queries/s", "cores": 1, "kind": "port",
+                    "sample": "first %d pairs of the same table, oracle, single thread" % SP,
+                    "mismatches_vs_device": bad}
             mp.close()
             del pairs, uu, vv, ones8, invz, ur, claimed, cobs, fl
         except Exception as e:  # noqa: BLE001
@@ -456,8 +709,13 @@ def main():
         ex.close()
         frames = d_kps = d_desc = d_n = None
         torch.cuda.empty_cache()
-        for name, (w2, h2, nf2, b2, ch2) in {"kitti_1241x376_2000kp": (1241, 376, 2000, 1024, 256),
-                                              "uhd_3840x2160_10000kp": (3840, 2160, 10000, 128, 32)}.items():
+        try:
+            extra["kitti_1241x376_2000kp"] = kitti_pipeline(dev, stream, barrier, synth, ORBextractor, ORBmatcher,
+                                                            cpu=not args.no_cpu)
+        except Exception as e:  # noqa: BLE001
+            extra["kitti_1241x376_2000kp"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        for name, (w2, h2, nf2, b2, ch2) in {"uhd_3840x2160_10000kp": (3840, 2160, 10000, 128, 32)}.items():
             try:
                 e2 = ORBextractor(nf2, 1.2, NLEVELS, 20, 7, max_width=w2, max_height=h2, max_batch=ch2, device=local_rank)
                 e2.set_stream(stream.cuda_stream)

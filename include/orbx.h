@@ -76,6 +76,8 @@ typedef struct orbx_config {
 typedef struct orbx_handle orbx_handle;
 
 const char* orbx_last_error(void);
+/* "orbx <major>.<minor> (gfx950)".  0.2: orbx_set_stream / orbm_set_stream take NULL as the legacy default
+ * stream (0.1 took it as "back to the handle's own stream"; that is orbx_reset_stream / orbm_reset_stream now). */
 const char* orbx_version(void);
 
 /* ORBextractor::ORBextractor (reference src/ORBextractor.cc:399-466). */
@@ -415,6 +417,22 @@ int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const o
                                 const float* scale_factors, const float* inv_scale_factors, float mb,
                                 float mbf, float* u_right, float* depth, int* n_stereo, int mem_space);
 
+/* Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for a table of independent rectified
+ * pairs in one set of launches: the stereo step of a batch of frames whose two images were extracted
+ * with orbx_extract_batch (the Frame constructor runs it once per stereo frame, src/Frame.cc:118-152).
+ * Every array a job points to, the pyramid levels included, is DEVICE memory (the table itself is host
+ * memory); arguments as in orbm_compute_stereo_matches; all jobs share the scale tables, mb and mbf and
+ * have pyramids of `nlevels` levels.  n_stereo is written on return (the call is synchronous). */
+typedef struct orbm_stereo_job {
+    orbm_frame left, right;
+    orbm_pyramid pyr_left, pyr_right;
+    float* u_right; /* left.n, out */
+    float* depth;   /* left.n, out */
+    int32_t n_stereo; /* out */
+} orbm_stereo_job;
+int orbm_compute_stereo_matches_batch(orbm_context* m, orbm_stereo_job* jobs, int njobs, const float* scale_factors,
+                                      const float* inv_scale_factors, int nlevels, float mb, float mbf);
+
 /* Many independent frame pairs in one call: orbm_search_by_projection for every entry of
  * `pairs`, each with the meaning of the arguments of the same name above.  Every array a
  * pair points to is DEVICE memory (the pair table itself is host memory); cur_claimed /
@@ -501,8 +519,9 @@ int orbm_knn2(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int n
               int mem_space);
 
 /* Debug tap: which form of the scan orbm_knn2 runs.  0 = chosen by problem size (the default),
- * 1 = vector ALU (xor + popcount), 2 = matrix cores (int8 contraction).  Both give the same
- * results; the tap exists so that tests and measurements can run either on any size. */
+ * 1 = vector ALU (xor + popcount), 2 = matrix cores (block-scaled fp4 / e2m1 contraction,
+ * v_mfma_scale_f32_32x32x64_f8f6f4).  Both give the same results; the tap exists so that tests and
+ * measurements can run either on any size. */
 int orbm_debug_knn_path(orbm_context* m, int path);
 
 /* ---- bag-of-words transform ----
@@ -543,8 +562,11 @@ int orbm_ratio_test(orbm_context* m, int nq, const int32_t* best_d, const int32_
  * aligned); the call only enqueues kernels on the context's stream and calls no hipMalloc,
  * hipFree or other allocating routine.  Its partial results live in a 12 MiB array that is part
  * of the library's code object on every GPU it runs on.  Limits: nq <= 1048576 and nt <= 4194304
- * (ORBX_ERR_CAPACITY beyond).  All calls on one GPU share that array: calls that overlap in time
- * on one GPU (two contexts, two streams) race and must be serialised by the caller. */
+ * (ORBX_ERR_CAPACITY beyond).  All calls on one GPU share that array.  Calls made outside graph
+ * capture are ordered by the library: each waits, on the device, for the previous call on that GPU
+ * (an event made in orbm_create), so two contexts on two streams or two host threads do not race.
+ * Calls made under graph capture cannot take part in that ordering: graphs that contain this entry
+ * point must not run at the same time as another use of it on the same GPU. */
 int orbm_knn2_noalloc(orbm_context* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
                       int train_index_base, int32_t* best_idx, int32_t* best_d, int32_t* second_d);
 

@@ -61,6 +61,11 @@ class ProjectionPair(C.Structure):
                 ("query_best", C.c_void_p), ("nmatches", C.c_int32)]
 
 
+class StereoJob(C.Structure):
+    _fields_ = [("left", MFrame), ("right", MFrame), ("pyr_left", Pyramid), ("pyr_right", Pyramid),
+                ("u_right", C.c_void_p), ("depth", C.c_void_p), ("n_stereo", C.c_int32)]
+
+
 class ProjectedJob(C.Structure):
     _fields_ = [("train", MFrame), ("train_u_right", C.c_void_p), ("q", ProjQueries), ("claimed", C.c_void_p),
                 ("claimed_obs", C.c_void_p), ("query_best", C.c_void_p), ("nmatches", C.c_int32)]
@@ -150,6 +155,7 @@ SIGNATURES = {
     "orbm_distinctive_descriptors": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i]),
     "orbm_compute_stereo_matches": (_i, [_vp, C.POINTER(MFrame), C.POINTER(MFrame), C.POINTER(Pyramid),
                                          C.POINTER(Pyramid), _vp, _vp, _f, _f, _vp, _vp, _vp, _i]),
+    "orbm_compute_stereo_matches_batch": (_i, [_vp, C.POINTER(StereoJob), _i, _vp, _vp, _i, _f, _f]),
     "orbm_search_by_projection_batch": (_i, [_vp, C.POINTER(ProjectionPair), _i, _vp, _i, _f, _f, _i]),
     "orbm_search_by_bow_batch": (_i, [_vp, C.POINTER(BowJob), _i, _i, _f, _i]),
     "orbm_search_for_initialization_batch": (_i, [_vp, C.POINTER(InitJob), _i, _i, _f, _i]),

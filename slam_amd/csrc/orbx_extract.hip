@@ -3154,7 +3154,7 @@ int check_device_error(orbx_handle* h) {
 
 extern "C" {
 
-const char* orbx_version(void) { return "orbx 0.1 (gfx950)"; }
+const char* orbx_version(void) { return "orbx 0.2 (gfx950)"; }
 
 int orbx_create(const orbx_config* cfg, orbx_handle** out) {
     if (!cfg || !out) {

@@ -1862,8 +1862,7 @@ struct StereoParams {
     float mbf, maxD;
 };
 
-__global__ void k_stereo_rows(DevFrame right, StereoParams sp, int4* rows) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void stereo_rows_body(const DevFrame& right, const StereoParams& sp, int4* rows, int i) {
     if (i >= right.n) return;
     const orbx_keypoint kp = right.kps[i];
     int4 o = make_int4(1, 0, kp.octave, __float_as_int(kp.x));  // empty band for an octave outside the pyramid
@@ -1875,6 +1874,10 @@ __global__ void k_stereo_rows(DevFrame right, StereoParams sp, int4* rows) {
     rows[i] = o;
 }
 
+__global__ void k_stereo_rows(DevFrame right, StereoParams sp, int4* rows) {
+    stereo_rows_body(right, sp, rows, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1884,11 +1887,9 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // One wave per left keypoint: descriptor argmin over the row band, then the 11x11 SAD
 // search over 11 column shifts on the keypoint's pyramid level and the parabola fit.
 // sad[iL] receives the best SAD (the key of the later median cut) or -1.
-__global__ __launch_bounds__(256) void k_stereo_match(DevFrame left, DevFrame right, const int4* __restrict__ rows,
-                                                      DevPyramid pl, DevPyramid pr, StereoParams sp, float* uRight,
-                                                      float* depth, int* sad) {
-    const int lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void stereo_match_body(const DevFrame& left, const DevFrame& right, const int4* __restrict__ rows,
+                                                  const DevPyramid& pl, const DevPyramid& pr, const StereoParams& sp,
+                                                  float* uRight, float* depth, int* sad, int iL, int lane) {
     if (iL >= left.n) return;
     const orbx_keypoint kpL = left.kps[iL];
     const float uL = kpL.x, vL = kpL.y;
@@ -1999,11 +2000,18 @@ __global__ __launch_bounds__(256) void k_stereo_match(DevFrame left, DevFrame ri
     }
 }
 
+__global__ __launch_bounds__(256) void k_stereo_match(DevFrame left, DevFrame right, const int4* __restrict__ rows,
+                                                      DevPyramid pl, DevPyramid pr, StereoParams sp, float* uRight,
+                                                      float* depth, int* sad) {
+    stereo_match_body(left, right, rows, pl, pr, sp, uRight, depth, sad, blockIdx.x * 4 + (threadIdx.x >> 6),
+                      threadIdx.x & 63);
+}
+
 // :763-774: median of the accepted SAD distances (element size/2 of the sorted list),
 // then every match with distance >= 1.5*1.4*median is dropped.  SAD <= 121*510, so the
 // median comes from two LDS histogram passes (high bits, then low bits).
-__global__ __launch_bounds__(1024) void k_stereo_median(int n, const int* __restrict__ sad, float* uRight, float* depth,
-                                                        int* kept) {
+__device__ __forceinline__ void stereo_median_body(int n, const int* __restrict__ sad, float* uRight, float* depth,
+                                                   int* kept) {
     __shared__ int hist[1024];
     __shared__ int sh[4];
     const int tid = threadIdx.x;
@@ -2073,6 +2081,40 @@ __global__ __launch_bounds__(1024) void k_stereo_median(int n, const int* __rest
         __syncthreads();
         if (tid == 0) *kept = sh[3];
     }
+}
+
+__global__ __launch_bounds__(1024) void k_stereo_median(int n, const int* __restrict__ sad, float* uRight, float* depth,
+                                                        int* kept) {
+    stereo_median_body(n, sad, uRight, depth, kept);
+}
+
+// The same three steps for a table of independent rectified pairs (blockIdx.y / blockIdx.x = pair).
+struct StereoJob {
+    DevFrame left, right;
+    DevPyramid pl, pr;
+    int4* rows;
+    int* sad;
+    float *uRight, *depth;
+    int* kept;
+    int nRows;
+};
+
+__global__ void k_stereo_rows_jobs(const StereoJob* __restrict__ jobs, StereoParams sp) {
+    const StereoJob& J = jobs[blockIdx.y];
+    stereo_rows_body(J.right, sp, J.rows, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_stereo_match_jobs(const StereoJob* __restrict__ jobs, StereoParams sp) {
+    const StereoJob& J = jobs[blockIdx.y];
+    if ((int)blockIdx.x * 4 >= J.left.n) return;
+    sp.nRows = J.nRows;
+    stereo_match_body(J.left, J.right, J.rows, J.pl, J.pr, sp, J.uRight, J.depth, J.sad,
+                      blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+__global__ __launch_bounds__(1024) void k_stereo_median_jobs(const StereoJob* __restrict__ jobs) {
+    const StereoJob& J = jobs[blockIdx.x];
+    stereo_median_body(J.left.n, J.sad, J.uRight, J.depth, J.kept);
 }
 
 // Each thread keeps KNN_QPT query descriptors in registers.  Every thread of the grid walks
@@ -2517,6 +2559,10 @@ namespace {
 const int MAX_DEVICES = 64;
 std::mutex g_scratchMu;
 int* g_scratchPtr[MAX_DEVICES] = {nullptr};  // device address of `scratch` on each GPU
+// Calls that share a GPU's array are ordered on the device: each waits for the event the previous one
+// recorded behind its merge kernel (created with the address, so that the entry point itself creates nothing).
+hipEvent_t g_scratchEv[MAX_DEVICES] = {nullptr};
+bool g_scratchEvRecorded[MAX_DEVICES] = {false};
 
 // With `device` current: the address of that GPU's copy of `scratch`, looked up once.
 int scratch_address(int device, int** out) {
@@ -2532,6 +2578,7 @@ int scratch_address(int device, int** out) {
             orbx_set_error("hipGetSymbolAddress returned a null address");
             return ORBX_ERR_HIP;
         }
+        ORBX_HIP_CHECK(hipEventCreateWithFlags(&g_scratchEv[device], hipEventDisableTiming));
         g_scratchPtr[device] = (int*)p;
     }
     *out = g_scratchPtr[device];
@@ -3724,6 +3771,82 @@ int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const o
     return ORBX_OK;
 }
 
+int orbm_compute_stereo_matches_batch(orbm_context* m, orbm_stereo_job* jobsIn, int njobs, const float* scale_factors,
+                                      const float* inv_scale_factors, int nlevels, float mb, float mbf) {
+    int rc = use_device(m);
+    if (rc) return rc;
+    if (njobs < 0 || (njobs > 0 && !jobsIn) || !scale_factors || !inv_scale_factors || nlevels < 1 || nlevels > MAX_LEVELS) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    if (njobs == 0) return ORBX_OK;
+    size_t rowsTotal = 0, sadTotal = 0;
+    int maxL = 0, maxR = 0;
+    for (int i = 0; i < njobs; i++) {
+        const orbm_stereo_job& P = jobsIn[i];
+        if (P.left.n < 0 || P.right.n < 0 || P.left.n > 65000 || P.right.n > 65000 ||
+            (P.left.n > 0 && (!P.u_right || !P.depth)) || P.pyr_left.nlevels != nlevels || P.pyr_right.nlevels != nlevels) {
+            orbx_set_error("stereo job %d: invalid argument", i);
+            return ORBX_ERR_INVALID;
+        }
+        rowsTotal += (size_t)P.right.n;
+        sadTotal += (size_t)P.left.n;
+        maxL = std::max(maxL, P.left.n);
+        maxR = std::max(maxR, P.right.n);
+    }
+    void *dJobs, *dRows, *dSad, *dKept;
+    if ((rc = pool_get(m, SL_JB_JOBS, (size_t)njobs * sizeof(StereoJob), &dJobs)) ||
+        (rc = pool_get(m, SL_ST_ROWS, std::max(rowsTotal, (size_t)1) * sizeof(int4), &dRows)) ||
+        (rc = pool_get(m, SL_ST_SAD, std::max(sadTotal, (size_t)1) * sizeof(int), &dSad)) ||
+        (rc = pool_get(m, SL_JB_TOT, (size_t)njobs * sizeof(int), &dKept)))
+        return rc;
+    StereoJob* jobs = (StereoJob*)arena_alloc(m, (size_t)njobs * sizeof(StereoJob));
+    if (!jobs) return ORBX_ERR_HIP;
+    size_t ro = 0, so = 0;
+    for (int i = 0; i < njobs; i++) {
+        const orbm_stereo_job& P = jobsIn[i];
+        StereoJob& J = jobs[i];
+        memset(&J, 0, sizeof(J));
+        if ((rc = fill_pyramid(&P.pyr_left, &J.pl, "left"))) return rc;
+        if ((rc = fill_pyramid(&P.pyr_right, &J.pr, "right"))) return rc;
+        if ((rc = make_frame(m, &P.left, 0, 0, ORBX_MEM_DEVICE, &J.left))) return rc;
+        if ((rc = make_frame(m, &P.right, 0, 0, ORBX_MEM_DEVICE, &J.right))) return rc;
+        J.rows = (int4*)dRows + ro;
+        J.sad = (int*)dSad + so;
+        J.uRight = P.u_right;
+        J.depth = P.depth;
+        J.kept = (int*)dKept + i;
+        J.nRows = J.pl.h[0];  // reference src/Frame.cc:610
+        ro += (size_t)P.right.n;
+        so += (size_t)P.left.n;
+    }
+    ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, (size_t)njobs * sizeof(StereoJob), hipMemcpyHostToDevice, m->stream));
+    StereoParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.nlevels = nlevels;
+    for (int l = 0; l < nlevels; l++) {
+        sp.scale[l] = scale_factors[l];
+        sp.invScale[l] = inv_scale_factors[l];
+    }
+    sp.mbf = mbf;
+    sp.maxD = mbf / mb;  // reference src/Frame.cc:633-636
+    if (maxR) {
+        ORBM_LAUNCH(k_stereo_rows_jobs, dim3((maxR + 255) / 256, njobs), dim3(256), 0, m->stream, (const StereoJob*)dJobs, sp);
+        ORBX_HIP_CHECK(hipGetLastError());
+    }
+    if (maxL) {
+        ORBM_LAUNCH(k_stereo_match_jobs, dim3((maxL + 3) / 4, njobs), dim3(256), 0, m->stream, (const StereoJob*)dJobs, sp);
+        ORBX_HIP_CHECK(hipGetLastError());
+    }
+    ORBM_LAUNCH(k_stereo_median_jobs, dim3(njobs), dim3(1024), 0, m->stream, (const StereoJob*)dJobs);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if ((int)m->totalsHost.size() < njobs) m->totalsHost.resize(njobs);
+    if ((rc = d2h(m, m->totalsHost.data(), dKept, (size_t)njobs * sizeof(int)))) return rc;
+    ORBX_HIP_CHECK(sync_deliver(m));
+    for (int i = 0; i < njobs; i++) jobsIn[i].n_stereo = m->totalsHost[i];
+    return ORBX_OK;
+}
+
 // Start state of the vocabulary-guided searches in one launch: match tables and bins at -1, histogram at 0.
 __global__ void k_bow_init(int* a, int na, int* b, int nb, int* c, int nc, int* zero, int nz) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -4345,6 +4468,16 @@ int orbm_knn2_noalloc(orbm_context* m, const uint8_t* q, int nq, const uint8_t* 
     }
     int *pi = base, *pd = base + KNN_NA_MAX_PART, *ps = base + 2 * KNN_NA_MAX_PART;
     const KnnPlan p = knn_plan(m->knnPath, nq, nt, KNN_NA_MAX_PART, true);
+    // Every context of this GPU shares the one array, and contexts default to streams of their own: the
+    // calls are put in one order (the mutex) and each waits on the device for the one before it (the
+    // event), so two matchers on two host threads cannot overwrite each other's partials.  A stream under
+    // graph capture cannot wait for or record an event of the outside world: there the caller orders
+    // the graph against other users of this entry point.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool ordered = hipStreamIsCapturing(m->stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+    if (!ordered) (void)hipGetLastError();
+    std::lock_guard<std::mutex> lock(g_scratchMu);
+    if (ordered && g_scratchEvRecorded[m->device]) ORBX_HIP_CHECK(hipStreamWaitEvent(m->stream, g_scratchEv[m->device], 0));
     if (p.mfma && nt > 0)
         hipLaunchKernelGGL(k_knn2_mfma, dim3(p.blocks, p.slices), dim3(256), 0, m->stream, (const uint4*)q, nq, (const uint4*)t,
                            nt, train_index_base, pi, pd, ps, 0, p.sliceRows);
@@ -4354,6 +4487,10 @@ int orbm_knn2_noalloc(orbm_context* m, const uint8_t* q, int nq, const uint8_t* 
     hipLaunchKernelGGL(k_knn2_merge_slices, dim3((nq + 255) / 256), dim3(256), 0, m->stream, nq, p.slices, (const int*)pi,
                        (const int*)pd, (const int*)ps, (int*)best_idx, (int*)best_d, (int*)second_d);
     ORBX_HIP_CHECK(hipGetLastError());
+    if (ordered) {
+        ORBX_HIP_CHECK(hipEventRecord(g_scratchEv[m->device], m->stream));
+        g_scratchEvRecorded[m->device] = true;
+    }
     return ORBX_OK;
 }
 

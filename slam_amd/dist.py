@@ -20,11 +20,14 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, force=False):
+    """Joins the process group of the torch.distributed.run environment.  A single process needs none and
+    gets none, unless `force` asks for a group of one (the collectives of knn2_sharded then run through the
+    backend with one rank: the way to exercise the RCCL calls on a one-GPU machine)."""
     import torch
     import torch.distributed as dist
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # ORBX_DIST_BACKEND=gloo lets several ranks rehearse on one GPU (RCCL wants one GPU per rank)
             backend = os.environ.get("ORBX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -53,21 +56,23 @@ def merge_partials(a, b):
     return idx.astype(np.int32), d.astype(np.int32), s.astype(np.int32)
 
 
-def knn2_sharded(q_local, t_local, t_offset, local_knn2, merge=merge_partials, group=None):
+def knn2_sharded(q_local, t_local, t_offset, local_knn2, merge=merge_partials, group=None, force_collectives=False):
     """Sharded brute-force kNN-2.
 
     q_local: this rank's slice of the queries, torch uint8 (nq_local, 32), equal on all ranks
              in length.  t_local: this rank's rows of the train set, whose first row has
     global index t_offset.  local_knn2(q_all, t_local, t_offset) -> (idx, d, second) int32
     tensors over ALL queries.  merge((ia,da,sa),(ib,db,sb)) merges two partials, a first.
-    Returns the merged (idx, d, second) for this rank's query slice.
+    Returns the merged (idx, d, second) for this rank's query slice.  With one rank nothing is exchanged,
+    unless force_collectives asks for the all-gather and the all-to-all to run anyway (a group of one must
+    then exist).
     """
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     nq = q_local.shape[0]
-    if world == 1:
+    if world == 1 and not (force_collectives and dist.is_initialized()):
         return local_knn2(q_local, t_local, t_offset)
     rccl = dist.get_backend(group) == "nccl"
 

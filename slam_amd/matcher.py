@@ -503,6 +503,37 @@ class ORBmatcher:
                                                     dp.ctypes.data, C.addressof(n), MEM_HOST))
         return ur[:len(kl)], dp[:len(kl)], n.value
 
+    @staticmethod
+    def stereo_job_table(jobs):
+        """The C table of orbm_compute_stereo_matches_batch for a list of job dicts (see
+        ComputeStereoMatchesBatch); reusable across calls while the tensors and pyramids stay alive."""
+        arr = (_lib.StereoJob * len(jobs))()
+        for i, p in enumerate(jobs):
+            arr[i].left = MFrame(p["kps_left"].data_ptr(), p["desc_left"].data_ptr(), p["kps_left"].shape[0], 0, 0, 1, 1)
+            arr[i].right = MFrame(p["kps_right"].data_ptr(), p["desc_right"].data_ptr(), p["kps_right"].shape[0], 0, 0, 1, 1)
+            arr[i].pyr_left = p["pyr_left"]
+            arr[i].pyr_right = p["pyr_right"]
+            arr[i].u_right = p["u_right"].data_ptr()
+            arr[i].depth = p["depth"].data_ptr()
+        return arr
+
+    def ComputeStereoMatchesBatch(self, jobs, ext_left, mb, mbf):
+        """Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for many rectified pairs in one set
+        of launches (device-resident).  `jobs`: a table from stereo_job_table, or a list of dicts: kps_left
+        (n, 28) u8, desc_left (n, 32) u8, kps_right, desc_right, u_right f32 (n, out), depth f32 (n, out) as
+        torch DEVICE tensors, and pyr_left / pyr_right from pyramid_of(extractor, frame).  ext_left supplies
+        the scale tables.  Returns the list of stereo point counts."""
+        arr = self.stereo_job_table(jobs) if isinstance(jobs, list) else jobs
+        sf = np.ascontiguousarray(ext_left.GetScaleFactors(), np.float32)
+        isf = np.ascontiguousarray(ext_left.GetInverseScaleFactors(), np.float32)
+        check(self._lib.orbm_compute_stereo_matches_batch(self._m, arr, len(arr), sf.ctypes.data, isf.ctypes.data, len(sf),
+                                                          float(mb), float(mbf)))
+        if len(arr) == 0:
+            return []
+        raw = np.frombuffer(arr, dtype=np.uint8).reshape(len(arr), C.sizeof(_lib.StereoJob))
+        off = _lib.StereoJob.n_stereo.offset
+        return raw[:, off:off + 4].copy().view(np.int32).reshape(-1).tolist()
+
     # ---- brute force
     def knn2(self, q, t, index_base=0):
         q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)

@@ -84,6 +84,33 @@ def synth_stereo_pair(w, h, seed, disparity_top, disparity_bottom, noise=0):
     return left, np.ascontiguousarray(right)
 
 
+def synth_stereo_sequence(w, h, seed, disparity_top, disparity_bottom, shifts, noise=0):
+    """Consecutive rectified stereo frames of one static scene: frame k is the window of the scene
+    displaced by shifts[k] = (dx, dy) pixels (|dx|, |dy| <= 16), with the disparities and the noise
+    model of synth_stereo_pair (the disparity changes at a fixed row of the scene; every image of
+    the sequence has its own noise).  Returns [(left, right), ...], (h, w) uint8 each."""
+    margin, vm = 64 + 16, 16
+    assert 0 <= disparity_top <= 64 and 0 <= disparity_bottom <= 64
+    scene = synth_image(w + 2 * margin, h + 2 * vm, seed)
+    split = vm + h // 2
+    out = []
+    for k, (dx, dy) in enumerate(shifts):
+        assert abs(dx) <= 16 and abs(dy) <= 16
+        x0, y0 = margin + dx, vm + dy
+        left = scene[y0:y0 + h, x0:x0 + w]
+        rows = np.arange(y0, y0 + h)
+        right = np.where((rows < split)[:, None], scene[y0:y0 + h, x0 + disparity_top:x0 + disparity_top + w],
+                         scene[y0:y0 + h, x0 + disparity_bottom:x0 + disparity_bottom + w])
+        imgs = []
+        for side, img in enumerate((left, right)):
+            if noise:
+                r = (hash_u64(seed, w * h, 80 + 2 * k + side) % np.uint64(2 * noise + 1)).astype(np.int32).reshape(h, w) - noise
+                img = np.clip(img.astype(np.int32) + r, 0, 255)
+            imgs.append(np.ascontiguousarray(img, dtype=np.uint8))
+        out.append(tuple(imgs))
+    return out
+
+
 def synth_descriptors(n, seed):
     """n random 256-bit descriptors as (n, 32) uint8."""
     v = hash_u64(seed, n * 4, 7)

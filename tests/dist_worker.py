@@ -20,7 +20,8 @@ from slam_amd.matcher import ORBmatcher  # noqa: E402
 
 def main():
     outdir, nq, nt, nframes = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    rank, _, world = sdist.init_process_group()
+    force = os.environ.get("ORBX_DIST_FORCE_COLLECTIVES") == "1"   # a group of one rank, exchange still made
+    rank, _, world = sdist.init_process_group(force=force)
     torch.cuda.set_device(0)   # every rank of this rehearsal shares the one GPU of the box
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
@@ -43,7 +44,7 @@ def main():
         m.knn2_merge_device(a[0], a[1], a[2], b[0], b[1], b[2])
         return a
 
-    bi, bd, sd = sdist.knn2_sharded(q_l, t_l, t0, local_knn2, merge)
+    bi, bd, sd = sdist.knn2_sharded(q_l, t_l, t0, local_knn2, merge, force_collectives=force)
     acc = torch.empty(nq_l, dtype=torch.uint8, device=dev)
     m.ratio_test_device(bd, sd, acc)
     # frame-sharded extraction: contiguous frame ranges, no collective

@@ -82,3 +82,29 @@ def test_two_ranks_hip_knn2_and_frame_sharding(tmp_path, oracle):
             assert np.array_equal(rd[f - f0, :n[f]], desc[f, :n[f]])
             covered += 1
     assert covered == nframes
+
+
+def test_rccl_collectives_with_one_rank(tmp_path, oracle):
+    """The RCCL branch of the sharded 2-NN (device all_gather_into_tensor of the queries, all_to_all_single
+    of the 12-byte partials, then the HIP merge) on the one GPU of the box: a process group of ONE rank on
+    the nccl backend, the exchange forced although one rank has nothing to exchange.  Result = the serial
+    scan; the frame-sharded extraction of the same worker covers all frames."""
+    nq, nt, nframes = 1 << 12, (1 << 15) + 7, 3
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(free_port()), ORBX_DIST_BACKEND="nccl", ORBX_DIST_FORCE_COLLECTIVES="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), str(nq), str(nt),
+                          str(nframes)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        o, _ = p.communicate(timeout=150)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise
+    assert p.returncode == 0, o.decode(errors="replace")[-2000:]
+    r = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    q, t, meta = synth.synth_knn_workload(nq, nt, seed=0xD35C)
+    oi, od, os_ = oracle.knn2(q, t, threads=8)
+    assert np.array_equal(r["bi"], oi) and np.array_equal(r["bd"], od) and np.array_equal(r["sd"], os_)
+    want = (od <= 50) & (od.astype(np.float32) < np.float32(0.6) * os_.astype(np.float32))
+    assert np.array_equal(r["acc"].astype(bool), want)
+    assert tuple(int(v) for v in r["frames"]) == (0, nframes)

@@ -325,6 +325,41 @@ def test_passes_in_flight_equal_single_frames(oracle):
         one.close()
 
 
+def test_null_stream_then_reset_stream_with_passes_in_flight():
+    """set_stream(NULL) selects the legacy default stream (it does not mean "back to the handle's own
+    stream": that is reset_stream).  A multi-pass device batch gives the same bytes on the handle's own
+    stream, on the null stream, and on the own stream again after reset_stream."""
+    import torch
+    from slam_amd.extractor import ORBextractor
+    from slam_amd import _lib
+    assert b"0.2" in _lib.load().orbx_version()
+    B, chunk = 20, 8
+    frames = synth.synth_batch_torch(B, 640, 480, 7300, device="cuda")
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=chunk)
+    try:
+        cap = ex.max_keypoints()
+        res = []
+        for mode in ("own", "null", "reset"):
+            if mode == "null":
+                ex.set_stream(None)
+            elif mode == "reset":
+                ex.reset_stream()
+            k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+            d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+            n = torch.zeros(B, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ex.extract_batch_device(frames, k, d, n, cap)
+            ex.synchronize()
+            torch.cuda.synchronize()
+            res.append((k.cpu().numpy(), d.cpu().numpy(), n.cpu().numpy()))
+        assert res[0][2].min() > 900
+        for r in res[1:]:
+            for a, b in zip(res[0], r):
+                assert np.array_equal(a, b)
+    finally:
+        ex.close()
+
+
 @pytest.mark.parametrize("no_repack", ["0", "1"])
 def test_width_not_multiple_of_four_device_resident(oracle, monkeypatch, no_repack):
     """KITTI-sized frames (1241 px wide) in device memory with rows padded to 1244 bytes take the
