@@ -330,11 +330,22 @@ def main():
         return el, prof
 
     passes = args.steps * ((B + ex.max_batch - 1) // ex.max_batch)
+    walk_note = None
     frames_per_launch = B * args.steps / passes
 
     def stage_table(prof):
         stages = {}
+        # The library's default schedule makes one walk per pyramid level that writes the blurred level AND the
+        # next level (k_level_walk): the blur stage then has no launches of its own and the "pyramid" stage
+        # stands for both, with the bytes of both (every level read once, levels 1.. and all blurred levels written).
+        walk = prof.get("blur", (0.0, 0))[1] == 0
+        ALG_BYTES["pyramid"] = (3 * sum(LEVEL_PX) - LEVEL_PX[0]) if walk else (sum(LEVEL_PX[:-1]) + sum(LEVEL_PX[1:]))
+        KERNEL_OF["pyramid"] = "k_level_walk" if walk else "k_pyramid_frame"
         for name, (ms, launches) in prof.items():
+            if launches == 0:
+                continue
+            if name == "pyramid" and walk:
+                launches = launches  # one timed interval per pass covers the eight walks
             per_launch_ms = ms / max(launches, 1)
             ent = {"ms_total": round(ms, 3), "launches": launches, "ms_per_launch": round(per_launch_ms, 4),
                    "us_per_frame": round(1000.0 * ms / (B * args.steps), 4)}

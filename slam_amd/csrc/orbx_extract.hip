@@ -902,6 +902,291 @@ __global__ __launch_bounds__(256) void k_blur_rows(Geom g, ImgRef img0, const u8
     }
 }
 
+// ------------------------------------------------------------------ one walk per level: blur + next level
+// A level is read ONCE: the row walk of k_blur_rows (a lane = 4 columns of the level, one 12-byte window
+// per row) also produces the next pyramid level (cv::resize INTER_LINEAR, arithmetic of resize_walk).  The
+// window of a lane holds both taps of every destination pixel whose first tap lies in the lane's own 4
+// columns: at most 4 consecutive pixels (scale factor > 1), whose horizontal sums, vertical combine and
+// rounding are those of the resize kernels.  Destination rows are not aligned with the lanes' columns, so
+// a finished row is regrouped across lanes: every lane packs its (at most 4) bytes into a word, and the
+// lane that stores destination word k fetches the words of the one or two lanes that hold its 4 pixels
+// (two ds_bpermute, one byte permutation) and stores 4 bytes.  A chunk of a row is a run of destination
+// words together with the W column groups that hold their taps (host table: first group, first word,
+// words); neighbouring chunks overlap by a group or two, whose blurred pixels are then stored twice with
+// the same value.  Lanes past the row's end or the batch's last frame stay active (the regrouping reads
+// every lane): their loads and stores fall outside the buffer descriptors, which return zero / drop them.
+struct WalkChunk {
+    int g0, k0, nk, pad;  // first column group, first destination word, destination words
+};
+struct WalkArgs {
+    ImgRef src;              // the level that is walked
+    int w, h;
+    u32 blurOff;             // inside a frame of the blurred block
+    int blurPitch;
+    int dw, dh, dstPitch;    // next level (dw = 0: none)
+    u32 dstOff;              // inside a frame of the pyramid block
+    const ResizeTap *xt, *st;  // column taps of the next level; per source row, the destination rows that finish on it
+    const u16* firstDest;    // per column group g: first destination pixel whose first tap lies in group >= g
+    const WalkChunk* chunks;
+    int nChunks, logW, bands, bandRows;  // bandRows: a multiple of the 7-row window
+};
+template <bool HALF_EVEN, bool RESIZE>
+__global__ __launch_bounds__(256) void k_level_walk(WalkArgs A, u8* __restrict__ pyr, i64 pyrFrameBytes, u8* __restrict__ blur,
+                                                     i64 blurFrameBytes, int k0, int k1, int k2, int k3, int nFrames) {
+    const int lane = threadIdx.x & 63;
+    const int task = (int)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (task >= A.bands * A.nChunks) return;
+    const int band = task / A.nChunks, chunk = task - band * A.nChunks;
+    const int4 CH = load_table<int4>(A.chunks + chunk);
+    const int logW = A.logW, K = 64 >> logW, Wm = (1 << logW) - 1;
+    const int li = lane & Wm, fk = lane >> logW;
+    const int f0 = (int)blockIdx.x * K;
+    const int Kv = min(K, nFrames - f0);  // frames of this wave that exist
+    const int w = A.w, h = A.h, G = (w + 3) >> 2;
+    const int gxr = CH.x + li;
+    const bool laneOn = gxr < G;
+    const int gx = min(gxr, G - 1);
+    const int srcPitch = A.src.pitch, dstPitch = A.blurPitch;
+    const __amdgpu_buffer_rsrc_t srcRs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(A.src.base + (i64)f0 * A.src.frameStride), 0, (int)((u32)Kv * (u32)A.src.frameStride), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dstRs = __builtin_amdgcn_make_buffer_rsrc((void*)(blur + (i64)f0 * blurFrameBytes + A.blurOff), 0,
+                                                                            (int)((u32)Kv * (u32)blurFrameBytes), 0x00020000);
+    const u32 OOB = 0x7FFFFFF0u;  // beyond every descriptor's size: such a store is dropped
+    const int wa = max(gx - 1, 0);
+    const int offS = (int)((u32)fk * (u32)A.src.frameStride) + 4 * wa;
+    const int offD = laneOn ? (int)((u32)fk * (u32)blurFrameBytes) + 4 * gx : (int)OOB;
+    const bool lastGroup = gx == G - 1 && gx > 0;
+    const u32 tailUp = (gx == G - 1 && (w & 3)) ? 1u : 0u;
+
+    // byte selectors for the 12 positions x = 4*gx-4 .. 4*gx+7 (as in k_blur_rows)
+    u32 selL = 0, selC = 0, selR = 0;
+#pragma unroll
+    for (int p = 0; p < 12; p++) {
+        const int x = min(max(4 * gx - 4 + p, -3), w + 2);
+        int xr = x < 0 ? -x : x;
+        xr = xr >= w ? 2 * (w - 1) - xr : xr;
+        const int gs = xr >> 2, bs = xr & 3;
+        u32 code;
+        if (p < 8) {
+            code = gs == wa + 1 ? 4 + bs : gs == wa ? bs : 4;
+        } else {
+            const int ga = lastGroup ? wa : wa + 2;
+            code = gs == wa + 1 ? 4 + bs : gs == ga ? bs : 4;
+        }
+        if (p < 4) selL |= code << (8 * p);
+        else if (p < 8) selC |= code << (8 * (p - 4));
+        else selR |= code << (8 * (p - 8));
+    }
+    const u32 W1 = (u32)k0 | ((u32)k1 << 8) | ((u32)k2 << 16) | ((u32)k3 << 24);
+    const u32 W2 = (u32)k2 | ((u32)k1 << 8) | ((u32)k0 << 16);
+    const int y0 = band * A.bandRows;
+    const int yEnd = min(y0 + A.bandRows, h);
+
+    // ---- the next level: this lane's destination pixels, and the destination word it stores
+    u32 rsel[4] = {0x0c0c0c0cu, 0x0c0c0c0cu, 0x0c0c0c0cu, 0x0c0c0c0cu}, rcoef[4] = {0, 0, 0, 0};
+    u32 selG = 0x0c0c0c0cu;
+    int addrA = 0, addrB = 0, offP = (int)OOB;
+    __amdgpu_buffer_rsrc_t pyrRs = dstRs;
+    const bool firstGroup = gx == 0;  // its own word is the first register of the window
+    if (RESIZE) {
+        pyrRs = __builtin_amdgcn_make_buffer_rsrc((void*)(pyr + (i64)f0 * pyrFrameBytes + A.dstOff), 0, (int)((u32)Kv * (u32)pyrFrameBytes),
+                                                  0x00020000);
+        const int dLo = 4 * CH.y, dHi = min(4 * (CH.y + CH.z), A.dw);  // destination pixels of this chunk
+        // pixels of this lane: first tap in its own 4 columns, inside the chunk's range
+        auto lane_range = [&](int g, int* b, int* e) {
+            *b = max((int)A.firstDest[g], dLo);
+            *e = min((int)A.firstDest[g + 1], dHi);
+        };
+        if (laneOn) {
+            int db, de;
+            lane_range(gx, &db, &de);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (db + j < de) {
+                    const ResizeTap t = A.xt[db + j];
+                    rsel[j] = (u32)(t.i0 - 4 * gx) | (12u << 8) | ((u32)(t.i1 - 4 * gx) << 16) | (12u << 24);
+                    rcoef[j] = (u32)(u16)t.c0 | ((u32)(u16)t.c1 << 16);
+                }
+            }
+        }
+        if (li < CH.z) {
+            const int kd = CH.y + li;
+            int sA = -1;
+            selG = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int d = 4 * kd + t;
+                u32 code = 12u;
+                if (d < A.dw) {
+                    const int gs = (int)(A.xt[d].i0 >> 2);
+                    if (sA < 0) sA = gs;
+                    int db, de;
+                    lane_range(gs, &db, &de);
+                    code = (u32)(d - db) + (gs == sA ? 0u : 4u);
+                }
+                selG |= code << (8 * t);
+            }
+            sA = max(sA, CH.x) - CH.x;
+            addrA = 4 * ((fk << logW) + sA);
+            addrB = 4 * ((fk << logW) + min(sA + 1, Wm));
+            offP = (int)((u32)fk * (u32)pyrFrameBytes) + 4 * kd;
+        }
+    }
+    u32 rprev[4] = {0, 0, 0, 0};
+    u32 two = 2;
+    asm volatile("" : "+v"(two));  // a vector register for the byte-inserting shifts below
+
+    typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+    auto fetch = [&](int y) {
+        y = min(y, h + 2);
+        int r = y < 0 ? -y : y;
+        r = r >= h ? 2 * (h - 1) - r : r;
+        return __builtin_amdgcn_raw_buffer_load_b96(srcRs, offS, r * srcPitch, 0);
+    };
+    auto hrow = [&](const u32x3& rw, u32* hs) {
+        const u32 a = rw[0], c = rw[1], b = rw[2];
+        const u32 Lw = __builtin_amdgcn_perm(c, a, selL);
+        const u32 Cw = __builtin_amdgcn_perm(c, a, selC);
+        const u32 Rw = __builtin_amdgcn_perm(c, lastGroup ? a : b, selR);
+        hs[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), W2,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), W1, 0u, false), false);
+        hs[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), W2,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), W1, 0u, false), false);
+        hs[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), W2,
+                                       __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), W1, 0u, false), false);
+        hs[3] = __builtin_amdgcn_udot4(Rw, W2, __builtin_amdgcn_udot4(Cw, W1, 0u, false), false);
+    };
+    // One source row of the next level's resize: horizontal sums of the lane's pixels; `tab` names the (at
+    // most two) destination rows whose second tap is this row (all of it scalar).
+    auto rz_row = [&](const u32x3& rw, bool emit, const uint4& tab) {
+        const u32 lo = firstGroup ? rw[0] : rw[1], hi = firstGroup ? rw[1] : rw[2];
+        u32 rcur[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            rcur[j] = __builtin_amdgcn_udot2(as_u16x2(__builtin_amdgcn_perm(hi, lo, rsel[j])), as_u16x2(rcoef[j]), 0u, false) >> 4;
+        if (emit) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const u32 w0 = e == 0 ? tab.x : tab.z, w1 = e == 0 ? tab.y : tab.w;
+                const int y = (int)(w0 & 0xffffu);
+                if (y != 0xffff) {          // scalar branch
+                    if ((w0 >> 16) != 0) {  // both taps are this row (clamped border)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) rprev[j] = rcur[j];
+                        asm volatile("" : "+v"(rprev[0]), "+v"(rprev[1]), "+v"(rprev[2]), "+v"(rprev[3]));
+                    }
+                    const u32 b0 = w1 << 16, b1 = w1 & 0xffff0000u;
+                    u32 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = __umulhi(b0, rprev[j]) + __umulhi(b1, rcur[j]) + 2u;
+                    u32 out = v[0] >> 2;
+                    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                        : "+v"(out)
+                        : "v"(two), "v"(v[1]));
+                    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                        : "+v"(out)
+                        : "v"(two), "v"(v[2]));
+                    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                        : "+v"(out)
+                        : "v"(two), "v"(v[3]));
+                    const u32 wA = (u32)__builtin_amdgcn_ds_bpermute(addrA, (int)out);
+                    const u32 wB = (u32)__builtin_amdgcn_ds_bpermute(addrB, (int)out);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(wB, wA, selG), pyrRs, offP, y * A.dstPitch, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) rprev[j] = rcur[j];
+    };
+    auto row_tab = [&](int s) { return load_table<uint4>(A.st + 2 * min(s, h - 1)); };
+
+    const u32 W01 = (u32)k0 | ((u32)k1 << 16), W23 = (u32)k2 | ((u32)k3 << 16), W21 = (u32)k2 | ((u32)k1 << 16),
+              W0h = (u32)k0 << 16;
+    u32 win[7][4], lastHs[4];
+    u32x3 cur[7];
+    {
+        u32x3 ini[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) ini[i] = fetch(y0 - 3 + i);
+#pragma unroll
+        for (int i = 0; i < 7; i++) cur[i] = fetch(y0 + 3 + i);
+        u32 h0[4], h1[4];
+        hrow(ini[0], h0);
+#pragma unroll
+        for (int i = 1; i < 6; i++) {
+            hrow(ini[i], h1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                win[i][k] = h0[k] | (h1[k] << 16);
+                h0[k] = h1[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) lastHs[k] = h0[k];
+        if (RESIZE) {
+            // the walk proper starts at row y0 + 3: the first band also owns rows 0..2 (the window's rows 3..5),
+            // every other band needs the sums of row y0 + 2 as the first "previous row"
+            if (y0 == 0) {
+                rz_row(ini[3], true, row_tab(0));
+                rz_row(ini[4], true, row_tab(1));
+                rz_row(ini[5], true, row_tab(2));
+            } else {
+                rz_row(ini[5], false, make_uint4(0, 0, 0, 0));
+            }
+        }
+    }
+    auto load_group = [&](u32x3* grp, int yFirst) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) grp[i] = fetch(yFirst + i);
+    };
+    auto run_group = [&](const u32x3* grp, int yb) {
+        uint4 tabs[7];
+        if (RESIZE) {
+#pragma unroll
+            for (int ph = 0; ph < 7; ph++) tabs[ph] = row_tab(yb + ph + 3);
+        }
+#pragma unroll
+        for (int ph = 0; ph < 7; ph++) {
+            const int y = yb + ph;
+            u32 hs[4];
+            hrow(grp[ph], hs);
+            u32 sv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 P3 = lastHs[k] | (hs[k] << 16);
+                win[(ph + 6) % 7][k] = P3;
+                lastHs[k] = hs[k];
+                u32 s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 1) % 7][k]), as_u16x2(W01), HALF_EVEN ? 0u : 32768u, false);
+                s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 3) % 7][k]), as_u16x2(W23), s, false);
+                s = __builtin_amdgcn_udot2(as_u16x2(win[(ph + 5) % 7][k]), as_u16x2(W21), s, false);
+                s = __builtin_amdgcn_udot2(as_u16x2(P3), as_u16x2(W0h), s, false);
+                if (HALF_EVEN) s += 0x7FFFu + (((s >> 16) & 1u) | tailUp);
+                sv[k] = min(s, 0xFFFFFFu);
+            }
+            const u32 lo = __builtin_amdgcn_perm(sv[1], sv[0], 0x0c0c0602u);
+            const u32 hi = __builtin_amdgcn_perm(sv[3], sv[2], 0x06020c0cu);
+            const u32 out = lo | hi;
+            if (y < yEnd) {  // scalar branch
+                __builtin_amdgcn_raw_buffer_store_b32(out, dstRs, offD, y * dstPitch, 0);
+                // row y + 3 is a row of this band's share of the next level unless it is a reflection
+                if (RESIZE && y + 3 < h) rz_row(grp[ph], true, tabs[ph]);
+            }
+        }
+    };
+    u32x3 other[7];
+    int yb = y0;
+    while (true) {
+        if (yb + 7 < yEnd) load_group(other, yb + 10);
+        run_group(cur, yb);
+        yb += 7;
+        if (yb >= yEnd) break;
+        if (yb + 7 < yEnd) load_group(cur, yb + 10);
+        run_group(other, yb);
+        yb += 7;
+        if (yb >= yEnd) break;
+    }
+}
+
 // ------------------------------------------------------------------ level-0 repack
 // Rows of a device-resident image whose base, row stride or frame stride is not a multiple of 4 (a
 // 1241-pixel-wide image with contiguous rows, say) are copied once to rows of a 64-byte-aligned pitch,
@@ -2292,6 +2577,15 @@ struct orbx_handle {
     int blurLds = 0;                       // ORBX_BLUR_LDS: unused LDS bytes per blur workgroup, caps its share of a compute unit (measurement knob)
     int resizeLogW = 0;                    // ORBX_RESIZE_LOGW: forces the lane split of the wave-uniform form (measurement knob)
     bool resizeRows = true;                // wave-uniform form of the streaming resize (ORBX_RESIZE_ROWS=0: per-lane form)
+    // one walk per level (k_level_walk: blurred level + next level from one pass over the rows)
+    struct WalkLevel {
+        size_t fdOff = 0, chOff[2] = {0, 0};  // byte offsets into dWalk: first-destination table, chunk tables for W = 64 / 32
+        int nCh[2] = {0, 0};
+    } walk[ORBX_MAX_LEVELS];
+    bool walkOk = false;                   // every level meets the walk's assumptions
+    int walkMode = 0;                      // ORBX_WALK=1: the walk where it applies (measured slower than the separate pyramid and blur kernels: both forms are bound by vector-instruction issue, not by bytes, and the walk issues more)
+    unsigned char* dWalk = nullptr;
+    size_t walkCap = 0;
     // scratch sized for scratchBatch frames of the current geometry
     int scratchBatch = 0;
     size_t scratchSig = 0;
@@ -2743,6 +3037,93 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
         A.st = h->dTaps + h->tapSOff[l];
         if (!h->resizeStreamOk[l] || A.sw < 8 || A.chunks > PYR_WAVES || (i64)A.sh * std::max(A.srcPitch, 1) > 0x7FFFFFFFll) h->pyrFrameOk = false;
     }
+    // tables of the one-walk-per-level kernel
+    {
+        if (const char* e = getenv("ORBX_WALK")) h->walkMode = atoi(e);
+        std::vector<unsigned char> wt;
+        auto pad16 = [&]() { wt.resize((wt.size() + 15) & ~(size_t)15, 0); };
+        bool ok = true;
+        for (int l = 0; l < g.nlevels && ok; l++) {
+            const LevelGeom& L = g.lv[l];
+            const int G = (L.w + 3) / 4;
+            const bool next = l + 1 < g.nlevels;
+            if (L.w < 8 || L.h < 4) ok = false;
+            std::vector<u16> fd((size_t)G + 1, 0);
+            const ResizeTap* xt = next ? taps.data() + h->tapXOff[l + 1] : nullptr;
+            const int dw = next ? g.lv[l + 1].w : 0, Gd = (dw + 3) / 4;
+            if (next && ok) {
+                if (!h->resizeStreamOk[l + 1]) ok = false;
+                for (int d = 0; d < dw && ok; d++) {
+                    if (xt[d].i1 < xt[d].i0 || xt[d].i1 - xt[d].i0 > 1 || (d > 0 && xt[d].i0 < xt[d - 1].i0)) ok = false;
+                }
+                int d = 0;
+                for (int gI = 0; gI <= G; gI++) {
+                    while (d < dw && (xt[d].i0 >> 2) < gI) d++;
+                    fd[(size_t)gI] = (u16)d;
+                }
+                for (int gI = 0; gI < G && ok; gI++)
+                    if (fd[(size_t)gI + 1] - fd[(size_t)gI] > 4) ok = false;  // a lane packs at most four pixels
+                for (int kd = 0; kd < Gd && ok; kd++)                          // a destination word gathers from at most two lanes
+                    for (int t = 1; t < 4; t++)
+                        if (4 * kd + t < dw && (xt[4 * kd + t].i0 >> 2) - (xt[4 * kd].i0 >> 2) > 1) ok = false;
+            }
+            pad16();
+            h->walk[l].fdOff = wt.size();
+            wt.insert(wt.end(), (unsigned char*)fd.data(), (unsigned char*)(fd.data() + fd.size()));
+            for (int wi = 0; wi < 2 && ok; wi++) {
+                const int Wd = wi == 0 ? 64 : 32;
+                std::vector<WalkChunk> ch;
+                int covered = 0;
+                if (next) {
+                    int k0 = 0;
+                    while (k0 < Gd && ok) {
+                        const int g0 = xt[4 * k0].i0 >> 2;
+                        while (g0 > covered) {
+                            ch.push_back(WalkChunk{covered, Gd, 0, 0});
+                            covered += Wd;
+                        }
+                        int nk = 0;
+                        while (k0 + nk < Gd) {
+                            bool fits = true;
+                            for (int t = 0; t < 4; t++) {
+                                const int d = 4 * (k0 + nk) + t;
+                                if (d < dw && (xt[d].i0 >> 2) - g0 > Wd - 1) fits = false;
+                            }
+                            if (!fits) break;
+                            nk++;
+                        }
+                        if (nk == 0) {
+                            ok = false;
+                            break;
+                        }
+                        ch.push_back(WalkChunk{g0, k0, nk, 0});
+                        covered = std::max(covered, g0 + Wd);
+                        k0 += nk;
+                    }
+                }
+                while (covered < G) {
+                    ch.push_back(WalkChunk{covered, Gd, 0, 0});
+                    covered += Wd;
+                }
+                pad16();
+                h->walk[l].chOff[wi] = wt.size();
+                h->walk[l].nCh[wi] = (int)ch.size();
+                wt.insert(wt.end(), (unsigned char*)ch.data(), (unsigned char*)(ch.data() + ch.size()));
+            }
+        }
+        h->walkOk = ok && g.nlevels >= 1;
+        if (h->walkOk) {
+            if (wt.size() > h->walkCap) {
+                free_dev(h->dWalk);
+                h->dWalk = nullptr;
+                h->walkCap = 0;
+                ORBX_HIP_CHECK(hipMalloc((void**)&h->dWalk, wt.size()));
+                h->walkCap = wt.size();
+            }
+            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
+            ORBX_HIP_CHECK(hipMemcpy(h->dWalk, wt.data(), wt.size(), hipMemcpyHostToDevice));
+        }
+    }
     // FAST cell records (reference src/ORBextractor.cc:799-817 for the ROI bounds)
     std::vector<FastCell> cells((size_t)g.totalCells);
     memset(cells.data(), 0, cells.size() * sizeof(FastCell));
@@ -2919,7 +3300,67 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
     const i64 imgBytes0 = (i64)(g.h - 1) * img0.pitch + g.w;
     const bool fusedPyramid = h->pyrFrameOk && h->resizeRows && imgBytes0 <= 0x7FFFFFFFll &&
                               (h->pyrFused >= 0 ? h->pyrFused != 0 : n >= 160);
-    if (fusedPyramid) {
+    // One walk per level (blurred level + next level) where the geometry allows it: level 0 word-aligned,
+    // 32-bit lane offsets for 64 frames of any of the three blocks.
+    const bool walk = h->walkOk && h->walkMode != 0 && h->blurRows && h->resizeRows &&
+                      ((((uintptr_t)img0.base) | (uintptr_t)img0.pitch | (uintptr_t)img0.frameStride) & 3u) == 0 &&
+                      img0.pitch >= align_up(g.w, 4) && (u64)img0.frameStride * 64 < 0x7FFFFFFFull &&
+                      (u64)g.pyrFrameBytes * 64 < 0x7FFFFFFFull && (u64)g.blurFrameBytes * 64 < 0x7FFFFFFFull;
+    if (walk) {
+        StageTimer t(h, ORBX_STAGE_PYRAMID);
+        for (int l = 0; l < g.nlevels; l++) {
+            const LevelGeom& L = g.lv[l];
+            const bool next = l + 1 < g.nlevels;
+            WalkArgs A;
+            memset(&A, 0, sizeof(A));
+            A.src = img0;
+            if (l > 0) {
+                A.src.base = h->dPyr + L.pyrOff;
+                A.src.frameStride = g.pyrFrameBytes;
+                A.src.pitch = L.pyrPitch;
+            }
+            A.w = L.w;
+            A.h = L.h;
+            A.blurOff = (u32)L.blurOff;
+            A.blurPitch = L.blurPitch;
+            if (next) {
+                A.dw = g.lv[l + 1].w;
+                A.dh = g.lv[l + 1].h;
+                A.dstPitch = g.lv[l + 1].pyrPitch;
+                A.dstOff = (u32)g.lv[l + 1].pyrOff;
+                A.xt = h->dTaps + h->tapXOff[l + 1];
+                A.st = h->dTaps + h->tapSOff[l + 1];
+            }
+            A.firstDest = (const u16*)(h->dWalk + h->walk[l].fdOff);
+            // lanes = W column groups x 64 / W frames: the split with the fewest idle lanes
+            const int G = (L.w + 3) / 4;
+            int wi = 0;
+            {
+                const double e64 = (double)G * n / ((double)h->walk[l].nCh[0] * 64 * n);
+                const double e32 = (double)G * n / ((double)h->walk[l].nCh[1] * 32 * ((n + 1) / 2) * 2);
+                if (e32 > e64 + 1e-9) wi = 1;
+                if (h->blurLogW == 6) wi = 0;
+                if (h->blurLogW == 5) wi = 1;
+            }
+            A.logW = wi == 0 ? 6 : 5;
+            A.chunks = (const WalkChunk*)(h->dWalk + h->walk[l].chOff[wi]);
+            A.nChunks = h->walk[l].nCh[wi];
+            // rows per band: BLUR_BH where that gives the launch enough waves to fill the GPU, fewer on the small
+            // levels (a band re-reads six rows of its neighbours)
+            const int K = 64 >> A.logW;
+            static const int wantWaves = getenv("ORBX_WALK_WAVES") ? atoi(getenv("ORBX_WALK_WAVES")) : 8192;
+            A.bandRows = BLUR_BH;
+            while (A.bandRows > 14 && (i64)((n + K - 1) / K) * A.nChunks * ((L.h + A.bandRows - 1) / A.bandRows) < wantWaves) A.bandRows -= 14;
+            A.bands = (L.h + A.bandRows - 1) / A.bandRows;
+            const int tasks = A.bands * A.nChunks;
+            dim3 grid((n + K - 1) / K, (tasks + 3) / 4, 1), block(256, 1, 1);
+            const bool he = h->cfg.blur_variant == 2;
+            auto kw = next ? (he ? k_level_walk<true, true> : k_level_walk<false, true>)
+                           : (he ? k_level_walk<true, false> : k_level_walk<false, false>);
+            hipLaunchKernelGGL(kw, grid, block, 0, st, A, h->dPyr, g.pyrFrameBytes, h->dBlur, g.blurFrameBytes, h->gaussK[0], h->gaussK[1],
+                               h->gaussK[2], h->gaussK[3], n);
+        }
+    } else if (fusedPyramid) {
         StageTimer t(h, ORBX_STAGE_PYRAMID);
         PyramidArgs args = h->pyrArgs;
         args.lv[1].srcPitch = img0.pitch;
@@ -2982,7 +3423,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
             }
         }
     }
-    const bool fork = h->overlapBlur && h->forkBlur && h->auxStream != nullptr;
+    const bool fork = !walk && h->overlapBlur && h->forkBlur && h->auxStream != nullptr;
     // forkBlur 1: the blur starts when the pyramid is done and runs beside FAST and the quadtree;
     // forkBlur 2: it starts when FAST is done and runs beside the quadtree only (FAST and the blur
     // both live on vector-instruction issue and slow each other down; the quadtree is a chain of
@@ -3068,7 +3509,7 @@ int run_pass(orbx_handle* h, ImgRef img0, int n, orbx_keypoint* dKps, u8* dDesc,
         }
         return ORBX_OK;
     };
-    if (!lateFork) {
+    if (!lateFork && !walk) {
         const int rc = launch_blur();
         if (rc != ORBX_OK) return rc;
     }
@@ -3229,7 +3670,7 @@ void orbx_destroy(orbx_handle* h) {
     }
     if (h->evStart) (void)hipEventDestroy(h->evStart);
     if (h->hErr) (void)hipHostFree(h->hErr);
-    free_dev(h->dTaps); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dRawStage); free_dev(h->dAlignStage); free_dev(h->dKpStage);
+    free_dev(h->dTaps); free_dev(h->dWalk); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dRawStage); free_dev(h->dAlignStage); free_dev(h->dKpStage);
     free_dev(h->dDescStage); free_dev(h->dNStage);
     for (int s = 0; s < ORBX_STAGE_COUNT; s++)
         for (auto& e : h->prof.ev[s]) {

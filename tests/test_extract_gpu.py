@@ -325,6 +325,29 @@ def test_passes_in_flight_equal_single_frames(oracle):
         one.close()
 
 
+@pytest.mark.parametrize("w,h,nf,blur", [(640, 480, 1000, 0), (1241, 376, 2000, 2), (333, 250, 400, 1)])
+def test_one_walk_per_level_equals_oracle(oracle, monkeypatch, w, h, nf, blur):
+    """ORBX_WALK=1: every level is read once by a kernel that writes its blurred image and the next
+    pyramid level (instead of the separate pyramid and blur kernels): same pyramid, same blurred images,
+    same keypoints and descriptors, for the three blur variants and lane splits of both widths."""
+    from slam_amd.extractor import ORBextractor
+    monkeypatch.setenv("ORBX_WALK", "1")
+    ex = ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=3, blur_variant=blur)
+    try:
+        imgs = synth.synth_batch(3, w, h, 900 + w)
+        kps, desc, n = ex.extract_batch(imgs)
+        p = oracle.params(nfeatures=nf, blur_variant=blur)
+        for f in range(3):
+            rk, rd = oracle.extract(p, imgs[f], cap=nf + 128)
+            assert_same_features(kps[f, :n[f]], desc[f, :n[f]], rk, rd, "walk %dx%d frame %d" % (w, h, f))
+        for lvl in range(8):
+            ref = oracle.pyramid_level(p, imgs[2], lvl)
+            assert np.array_equal(ex.image_pyramid_level(2, lvl), ref), "level %d" % lvl
+            assert np.array_equal(ex.debug_blurred(2, lvl), oracle.gaussian7(ref, blur)), "blurred level %d" % lvl
+    finally:
+        ex.close()
+
+
 def test_null_stream_then_reset_stream_with_passes_in_flight():
     """set_stream(NULL) selects the legacy default stream (it does not mean "back to the handle's own
     stream": that is reset_stream).  A multi-pass device batch gives the same bytes on the handle's own

@@ -44,7 +44,8 @@ def draw(rng):
     # launch form of the FAST kernel: 0 the library's choice (one launch for batches this small), 1 one launch,
     # 2 one launch per group of levels (what large batches get)
     return dict(w=w, h=h, scale=scale, nlevels=nlevels, nf=nf, ini=ini, mn=mn, kind=kind,
-                seed=int(rng.integers(1, 1 << 30)), batch=int(rng.choice([1, 2, 3])), groups=int(rng.choice([0, 1, 2, 2])))
+                seed=int(rng.integers(1, 1 << 30)), batch=int(rng.choice([1, 2, 3])), groups=int(rng.choice([0, 1, 2, 2])),
+                walk=int(rng.choice([0, 0, 1])))   # 1: one walk per level writes the blurred level and the next level
 
 
 def make_images(c):
@@ -73,6 +74,7 @@ def make_images(c):
 
 def run_one(c):
     os.environ["ORBX_FAST_GROUPS"] = str(c.get("groups", 0))   # read when the extractor lays out its buffers
+    os.environ["ORBX_WALK"] = str(c.get("walk", 0))
     ex = ORBextractor(c["nf"], c["scale"], c["nlevels"], c["ini"], c["mn"], max_width=c["w"],
                       max_height=c["h"], max_batch=c["batch"])
     try:
