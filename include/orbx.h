@@ -123,6 +123,13 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int h_
                        size_t row_stride, size_t img_stride, orbx_keypoint* kps, uint8_t* desc,
                        int cap_per_frame, int* n_out, int mem_space);
 
+/* Page-locks a host buffer the caller keeps using across calls (image batches, output arrays), so that
+ * host-space calls copy from / to it directly instead of through the handle's own pinned staging; a
+ * wrapper over hipHostRegister / hipHostUnregister for callers that do not link the HIP runtime.  It
+ * has no counterpart in the reference (whose images live in cv::Mat buffers, rgbd_tum.cc:77-119). */
+int orbx_register_host(void* ptr, size_t bytes);
+int orbx_unregister_host(void* ptr);
+
 /* mvImagePyramid[level] of frame `frame` of the last extract call (public
  * member read by Frame::ComputeStereoMatches, reference src/Frame.cc:610,700).
  * *ptr is DEVICE memory owned by the handle (level 0 aliases the caller's

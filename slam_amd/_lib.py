@@ -105,6 +105,8 @@ SIGNATURES = {
     "orbx_max_keypoints": (_i, [_vp]),
     "orbx_extract": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _i, C.POINTER(_i)]),
     "orbx_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _vp, _i, _vp, _i]),
+    "orbx_register_host": (_i, [_vp, _sz]),
+    "orbx_unregister_host": (_i, [_vp]),
     "orbx_get_level": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
                             C.POINTER(_sz)]),
     "orbx_levels": (_i, [_vp]),

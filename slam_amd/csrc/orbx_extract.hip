@@ -17,7 +17,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbx_pattern_31.h"
@@ -2533,6 +2537,68 @@ struct StageProfile {
 
 }  // namespace
 
+// Worker threads for the host-side copies of the host-memory path (caller's pageable images -> pinned
+// staging, pinned results -> caller's arrays): one thread moves about 10 GB/s, a pass of 640x480 frames
+// wants several times that.  run(n, fn) calls fn(0) .. fn(n - 1) on the workers and the calling thread.
+struct CopyPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cvDone;
+    std::function<void(int)> job;
+    int nTasks = 0, next = 0, pending = 0;
+    unsigned long long gen = 0;
+    bool stop = false;
+    explicit CopyPool(int workers) {
+        for (int i = 0; i < workers; i++) th.emplace_back([this] { loop(); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> l(mu);
+        while (true) {
+            cv.wait(l, [&] { return stop || (gen != seen && next < nTasks); });
+            if (stop) return;
+            while (next < nTasks) {
+                const int i = next++;
+                l.unlock();
+                job(i);
+                l.lock();
+                if (--pending == 0) cvDone.notify_all();
+            }
+            seen = gen;
+        }
+    }
+    void run(int n, const std::function<void(int)>& fn) {
+        if (n <= 0) return;
+        if (th.empty() || n == 1) {
+            for (int i = 0; i < n; i++) fn(i);
+            return;
+        }
+        std::unique_lock<std::mutex> l(mu);
+        job = fn;
+        nTasks = n;
+        next = 0;
+        pending = n;
+        gen++;
+        cv.notify_all();
+        while (next < nTasks) {  // the caller works too
+            const int i = next++;
+            l.unlock();
+            fn(i);
+            l.lock();
+            --pending;
+        }
+        cvDone.wait(l, [&] { return pending == 0; });
+    }
+};
+
 struct orbx_handle {
     orbx_config cfg;
     int device = 0;
@@ -2612,7 +2678,20 @@ struct orbx_handle {
         hipEvent_t evPyramid = nullptr, evBlur = nullptr, evDone = nullptr;
     } pipes[ORBX_PIPES];
     hipEvent_t evStart = nullptr;
-    // staging for host-memory calls
+    // staging for host-memory calls: a ring of slots, each a pass of frames in pinned host memory and in
+    // device memory plus that pass's outputs in both, so that the host copies of pass k + 1, the upload of
+    // pass k, the kernels of pass k - 1 and the download of pass k - 2 overlap
+    struct HostSlot {
+        u8 *pinIn = nullptr, *dIn = nullptr;
+        size_t inCap = 0;
+        u8 *pinOut = nullptr, *dOut = nullptr;  // keypoints, descriptors, counts of one pass
+        size_t outCap = 0;
+        hipEvent_t evIn = nullptr, evComp = nullptr, evOut = nullptr;
+        int f0 = 0, n = 0;
+        bool busy = false;
+    } hostSlots[3];
+    hipStream_t copyIn = nullptr, copyOut = nullptr;
+    struct CopyPool* pool = nullptr;
     u8* dImgStage = nullptr;
     size_t imgStageCap = 0;
     u8* dRawStage = nullptr;  // host rows as they are (any row stride), before the repack to the staged pitch
@@ -3591,6 +3670,151 @@ int check_device_error(orbx_handle* h) {
     return ORBX_OK;
 }
 
+// True when `p` is page-locked host memory the GPU can copy from directly (hipHostMalloc, hipHostRegister).
+bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary malloc'd pointer is "invalid value" to the runtime
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Host images in, host keypoints out (the shape of the reference's call: the Frame constructor owns a
+// cv::Mat).  Passes of `chunk` frames go through a ring of three slots: worker threads copy the caller's
+// rows into pinned memory at the staged pitch (pageable memory cannot be copied from asynchronously, and
+// one thread moves far less than the link does), an upload stream brings the slot to the device, the
+// handle's stream runs the kernels, a download stream returns the slot's results to pinned memory, and
+// the workers copy them to the caller's arrays: the host copy of pass k + 1, the upload of pass k, the
+// kernels of pass k - 1 and the download of pass k - 2 run side by side.  Images and output arrays that are
+// already page-locked (hipHostMalloc / hipHostRegister, orbx_register_host) skip the host copies.
+int extract_host_pipelined(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh, size_t row_stride, size_t img_stride,
+                           orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out, int chunk) {
+    const size_t sp = (size_t)align_up(w, 64);  // staged rows are padded to 64 bytes: aligned word loads everywhere
+    const size_t inBytes = (size_t)chunk * sp * hh;
+    const size_t kpBytes = (size_t)chunk * cap * sizeof(orbx_keypoint), dsBytes = (size_t)chunk * cap * 32;
+    const size_t outBytes = kpBytes + dsBytes + (((size_t)chunk * sizeof(int) + 255) & ~(size_t)255);
+    const int npass = (B + chunk - 1) / chunk;
+    const int S = std::min(3, npass);
+    if (!h->copyIn) {
+        ORBX_HIP_CHECK(hipStreamCreateWithFlags(&h->copyIn, hipStreamNonBlocking));
+        ORBX_HIP_CHECK(hipStreamCreateWithFlags(&h->copyOut, hipStreamNonBlocking));
+    }
+    if (!h->pool) {
+        int workers = 7;  // + the calling thread
+        if (const char* e = getenv("ORBX_HOST_THREADS")) workers = std::min(std::max(atoi(e) - 1, 0), 63);
+        workers = std::min(workers, std::max((int)std::thread::hardware_concurrency() - 1, 0));
+        h->pool = new CopyPool(workers);
+    }
+    for (int s = 0; s < S; s++) {
+        orbx_handle::HostSlot& H = h->hostSlots[s];
+        if (!H.evIn) {
+            ORBX_HIP_CHECK(hipEventCreateWithFlags(&H.evIn, hipEventDisableTiming));
+            ORBX_HIP_CHECK(hipEventCreateWithFlags(&H.evComp, hipEventDisableTiming));
+            ORBX_HIP_CHECK(hipEventCreateWithFlags(&H.evOut, hipEventDisableTiming));
+        }
+        if (H.inCap < inBytes) {
+            ORBX_HIP_CHECK(hipDeviceSynchronize());
+            if (H.pinIn) (void)hipHostFree(H.pinIn);
+            free_dev(H.dIn);
+            H.pinIn = H.dIn = nullptr;
+            H.inCap = 0;
+            ORBX_HIP_CHECK(hipHostMalloc((void**)&H.pinIn, inBytes + 256, hipHostMallocDefault));
+            ORBX_HIP_CHECK(hipMalloc((void**)&H.dIn, inBytes + 256));
+            H.inCap = inBytes;
+        }
+        if (H.outCap < outBytes) {
+            ORBX_HIP_CHECK(hipDeviceSynchronize());
+            if (H.pinOut) (void)hipHostFree(H.pinOut);
+            free_dev(H.dOut);
+            H.pinOut = H.dOut = nullptr;
+            H.outCap = 0;
+            ORBX_HIP_CHECK(hipHostMalloc((void**)&H.pinOut, outBytes, hipHostMallocDefault));
+            ORBX_HIP_CHECK(hipMalloc((void**)&H.dOut, outBytes));
+            H.outCap = outBytes;
+        }
+        H.busy = false;
+    }
+    const bool pinnedIn = is_pinned_host(imgs) && row_stride == sp && img_stride == sp * (size_t)hh;
+    const bool pinnedOut = is_pinned_host(kps) && is_pinned_host(desc) && is_pinned_host(n_out);
+    // results of the pass a slot holds: pinned staging -> the caller's arrays
+    auto deliver = [&](orbx_handle::HostSlot& H) -> int {
+        if (!H.busy) return ORBX_OK;
+        ORBX_HIP_CHECK(hipEventSynchronize(H.evOut));
+        H.busy = false;
+        if (pinnedOut) return ORBX_OK;
+        const int n = H.n, f0 = H.f0;
+        const int* cnt = (const int*)(H.pinOut + kpBytes + dsBytes);
+        memcpy(n_out + f0, cnt, (size_t)n * sizeof(int));
+        const u8* pk = H.pinOut;
+        const u8* pd = H.pinOut + kpBytes;
+        h->pool->run(n, [&](int f) {
+            // only the entries a frame produced travel on (the rest of its capacity holds nothing)
+            const size_t m = (size_t)std::min(std::max(cnt[f], 0), cap);
+            memcpy(kps + (size_t)(f0 + f) * cap, pk + (size_t)f * cap * sizeof(orbx_keypoint), m * sizeof(orbx_keypoint));
+            memcpy(desc + (size_t)(f0 + f) * cap * 32, pd + (size_t)f * cap * 32, m * 32);
+        });
+        return ORBX_OK;
+    };
+    int rc = ORBX_OK;
+    hipStream_t st = h->stream;
+    for (int k = 0; k < npass; k++) {
+        orbx_handle::HostSlot& H = h->hostSlots[k % S];
+        if ((rc = deliver(H))) return rc;  // also: the slot's previous kernels and download are done
+        const int f0 = k * chunk, n = std::min(chunk, B - f0);
+        H.f0 = f0;
+        H.n = n;
+        const u8* up = H.pinIn;
+        if (pinnedIn) {
+            up = imgs + (size_t)f0 * img_stride;
+        } else {
+            h->pool->run(n, [&](int f) {
+                const u8* src = imgs + (size_t)(f0 + f) * img_stride;
+                u8* dst = H.pinIn + (size_t)f * sp * hh;
+                if (row_stride == sp) {
+                    memcpy(dst, src, sp * (size_t)(hh - 1) + (size_t)w);
+                } else {
+                    for (int y = 0; y < hh; y++) memcpy(dst + (size_t)y * sp, src + (size_t)y * row_stride, (size_t)w);
+                }
+            });
+        }
+        ORBX_HIP_CHECK(hipMemcpyAsync(H.dIn, up, (size_t)n * sp * hh - (sp - (size_t)w), hipMemcpyHostToDevice, h->copyIn));
+        ORBX_HIP_CHECK(hipEventRecord(H.evIn, h->copyIn));
+        ORBX_HIP_CHECK(hipStreamWaitEvent(st, H.evIn, 0));
+        ImgRef img0;
+        img0.base = H.dIn;
+        img0.pitch = (int)sp;
+        img0.frameStride = (i64)sp * hh;
+        orbx_keypoint* dK = (orbx_keypoint*)H.dOut;
+        u8* dD = H.dOut + kpBytes;
+        int* dN = (int*)(H.dOut + kpBytes + dsBytes);
+        if ((rc = run_pass(h, img0, n, dK, dD, cap, dN))) return rc;
+        ORBX_HIP_CHECK(hipEventRecord(H.evComp, st));
+        ORBX_HIP_CHECK(hipStreamWaitEvent(h->copyOut, H.evComp, 0));
+        if (pinnedOut) {
+            ORBX_HIP_CHECK(hipMemcpyAsync(kps + (size_t)f0 * cap, dK, (size_t)n * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->copyOut));
+            ORBX_HIP_CHECK(hipMemcpyAsync(desc + (size_t)f0 * cap * 32, dD, (size_t)n * cap * 32, hipMemcpyDeviceToHost, h->copyOut));
+            ORBX_HIP_CHECK(hipMemcpyAsync(n_out + f0, dN, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->copyOut));
+        } else if (n == chunk) {
+            ORBX_HIP_CHECK(hipMemcpyAsync(H.pinOut, H.dOut, outBytes, hipMemcpyDeviceToHost, h->copyOut));
+        } else {
+            ORBX_HIP_CHECK(hipMemcpyAsync(H.pinOut, dK, (size_t)n * cap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, h->copyOut));
+            ORBX_HIP_CHECK(hipMemcpyAsync(H.pinOut + kpBytes, dD, (size_t)n * cap * 32, hipMemcpyDeviceToHost, h->copyOut));
+            ORBX_HIP_CHECK(hipMemcpyAsync(H.pinOut + kpBytes + dsBytes, dN, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->copyOut));
+        }
+        ORBX_HIP_CHECK(hipEventRecord(H.evOut, h->copyOut));
+        // (the next upload into this slot follows deliver(), which has waited for this download and so for these kernels)
+        H.busy = true;
+        h->lastImg0 = img0;
+        h->lastBatch = n;
+        h->lastFirstFrame = f0;
+    }
+    for (int k = npass; k < npass + S; k++)
+        if ((rc = deliver(h->hostSlots[k % S]))) return rc;
+    return check_device_error(h);
+}
+
 }  // namespace
 
 extern "C" {
@@ -3669,6 +3893,18 @@ void orbx_destroy(orbx_handle* h) {
         if (P.evDone) (void)hipEventDestroy(P.evDone);
     }
     if (h->evStart) (void)hipEventDestroy(h->evStart);
+    for (auto& H : h->hostSlots) {
+        if (H.pinIn) (void)hipHostFree(H.pinIn);
+        if (H.pinOut) (void)hipHostFree(H.pinOut);
+        free_dev(H.dIn);
+        free_dev(H.dOut);
+        if (H.evIn) (void)hipEventDestroy(H.evIn);
+        if (H.evComp) (void)hipEventDestroy(H.evComp);
+        if (H.evOut) (void)hipEventDestroy(H.evOut);
+    }
+    if (h->copyIn) (void)hipStreamDestroy(h->copyIn);
+    if (h->copyOut) (void)hipStreamDestroy(h->copyOut);
+    delete h->pool;
     if (h->hErr) (void)hipHostFree(h->hErr);
     free_dev(h->dTaps); free_dev(h->dWalk); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dRawStage); free_dev(h->dAlignStage); free_dev(h->dKpStage);
     free_dev(h->dDescStage); free_dev(h->dNStage);
@@ -3685,6 +3921,36 @@ void orbx_destroy(orbx_handle* h) {
     if (h->evBlur) (void)hipEventDestroy(h->evBlur);
     if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
     delete h;
+}
+
+int orbx_register_host(void* ptr, size_t bytes) {
+    if (!ptr || !bytes) {
+        orbx_set_error("invalid argument");
+        return ORBX_ERR_INVALID;
+    }
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // the failure must not surface in a later, unrelated call
+        e = hipHostRegister(ptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        orbx_set_error("hipHostRegister of %zu bytes failed: %s (the locked-memory limit of the process may be too small)", bytes,
+                       hipGetErrorString(e));
+        return ORBX_ERR_HIP;
+    }
+    return ORBX_OK;
+}
+
+int orbx_unregister_host(void* ptr) {
+    if (!ptr) return ORBX_OK;
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        orbx_set_error("hipHostUnregister failed: %s", hipGetErrorString(e));
+        return ORBX_ERR_HIP;
+    }
+    return ORBX_OK;
 }
 
 int orbx_set_stream(orbx_handle* h, void* hip_stream) {
@@ -3766,28 +4032,8 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
             ORBX_HIP_CHECK(hipStreamWaitEvent(h->pipes[p].st, h->evStart, 0));
         }
     }
-    if (mem_space == ORBX_MEM_HOST) {
-        const size_t imgBytes = (size_t)chunk * align_up(w, 64) * hh;
-        if (imgBytes > h->imgStageCap) {
-            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-            free_dev(h->dImgStage);
-            h->dImgStage = nullptr;
-            h->imgStageCap = 0;
-            ORBX_HIP_CHECK(hipMalloc((void**)&h->dImgStage, imgBytes + 256));
-            h->imgStageCap = imgBytes;
-        }
-        const size_t outN = (size_t)chunk * cap;
-        if (outN > h->outStageCap) {
-            ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-            free_dev(h->dKpStage); free_dev(h->dDescStage); free_dev(h->dNStage);
-            h->dKpStage = nullptr; h->dDescStage = nullptr; h->dNStage = nullptr;
-            h->outStageCap = 0;
-            ORBX_HIP_CHECK(hipMalloc((void**)&h->dKpStage, outN * sizeof(orbx_keypoint)));
-            ORBX_HIP_CHECK(hipMalloc((void**)&h->dDescStage, outN * 32));
-            ORBX_HIP_CHECK(hipMalloc((void**)&h->dNStage, (size_t)h->cfg.max_batch * sizeof(int)));
-            h->outStageCap = outN;
-        }
-    }
+    if (mem_space == ORBX_MEM_HOST)
+        return extract_host_pipelined(h, imgs, B, w, hh, row_stride, img_stride, kps, desc, cap, n_out, chunk);
     // Device-resident frames whose layout is not word-aligned are repacked pass by pass (ORBX_NO_REPACK=1
     // keeps the unaligned forms of the kernels, which the tests compare with the repacked path).
     const bool repackDevice = mem_space == ORBX_MEM_DEVICE && !h->noRepack && hh <= 65535 && chunk <= 65535 &&
@@ -3807,54 +4053,7 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
     for (int f0 = 0; f0 < B; f0 += chunk) {
         const int n = std::min(chunk, B - f0);
         ImgRef img0;
-        if (mem_space == ORBX_MEM_HOST) {
-            // staged rows are padded to 64 bytes so that every kernel can use aligned word loads
-            // A pitched copy from pageable host memory is issued row by row and is orders of magnitude
-            // slower than a linear one, so host rows always travel as linear copies: straight into the
-            // staging buffer when they already have its pitch, otherwise into a raw buffer that a
-            // device-side pitched copy repacks.
-            const size_t sp = (size_t)align_up(w, 64);
-            const bool packed = img_stride == row_stride * (size_t)hh;
-            const bool direct = row_stride == sp;
-            u8* land = h->dImgStage;
-            if (!direct) {
-                const size_t rawBytes = (size_t)n * row_stride * hh;
-                if (rawBytes > h->rawStageCap) {
-                    ORBX_HIP_CHECK(hipStreamSynchronize(h->stream));
-                    free_dev(h->dRawStage);
-                    h->dRawStage = nullptr;
-                    h->rawStageCap = 0;
-                    ORBX_HIP_CHECK(hipMalloc((void**)&h->dRawStage, (size_t)chunk * row_stride * hh + 256));
-                    h->rawStageCap = (size_t)chunk * row_stride * hh;
-                }
-                land = h->dRawStage;
-            }
-            const size_t frameBytes = row_stride * (size_t)(hh - 1) + (size_t)w;  // the last row may end at w
-            if (packed) {
-                ORBX_HIP_CHECK(hipMemcpyAsync(land, imgs + (size_t)f0 * img_stride, row_stride * (size_t)hh * (n - 1) + frameBytes,
-                                              hipMemcpyHostToDevice, h->stream));
-            } else {
-                for (int f = 0; f < n; f++)
-                    ORBX_HIP_CHECK(hipMemcpyAsync(land + (size_t)f * row_stride * hh, imgs + (size_t)(f0 + f) * img_stride,
-                                                  frameBytes, hipMemcpyHostToDevice, h->stream));
-            }
-            if (!direct)
-                ORBX_HIP_CHECK(hipMemcpy2DAsync(h->dImgStage, sp, h->dRawStage, row_stride, (size_t)w, (size_t)hh * n,
-                                                hipMemcpyDeviceToDevice, h->stream));
-            img0.base = h->dImgStage;
-            img0.pitch = (int)sp;
-            img0.frameStride = (i64)sp * hh;
-            rc = run_pass(h, img0, n, h->dKpStage, h->dDescStage, cap, h->dNStage);
-            if (rc) return rc;
-            ORBX_HIP_CHECK(hipMemcpyAsync(kps + (size_t)f0 * cap, h->dKpStage, (size_t)n * cap * sizeof(orbx_keypoint),
-                                          hipMemcpyDeviceToHost, h->stream));
-            ORBX_HIP_CHECK(hipMemcpyAsync(desc + (size_t)f0 * cap * 32, h->dDescStage, (size_t)n * cap * 32,
-                                          hipMemcpyDeviceToHost, h->stream));
-            ORBX_HIP_CHECK(hipMemcpyAsync(n_out + f0, h->dNStage, (size_t)n * sizeof(int), hipMemcpyDeviceToHost,
-                                          h->stream));
-            rc = check_device_error(h);
-            if (rc) return rc;
-        } else {
+        {
             img0.base = imgs + (size_t)f0 * img_stride;
             img0.pitch = (int)row_stride;
             img0.frameStride = (i64)img_stride;
