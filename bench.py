@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
-    ap.add_argument("--chunk", type=int, default=512, help="frames per internal pass")
-    ap.add_argument("--cpu-frames", type=int, default=1024, help="sample size of the CPU baseline")
+    ap.add_argument("--chunk", type=int, default=1024, help="frames per internal pass")
+    ap.add_argument("--cpu-frames", type=int, default=4096, help="sample size of the CPU baseline")
     ap.add_argument("--schedule", choices=["both", "default", "serial"], default="both",
                     help="default: only the timed region (the library's default schedule); both: also a serialised run; "
                          "serial: the timed region itself runs one pass at a time on one stream (for a kernel "
@@ -387,21 +387,25 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("source_hash") != src_hash:
                 traffic_note = "profiles/pmc_traffic.json was taken with other kernel sources (stale): not quoted"
-            elif dominant in tj and tj[dominant].get("frames_per_launch") == frames_per_launch:
-                traffic = tj[dominant]["hbm_bytes_per_launch"]
+            elif dominant in tj and tj[dominant].get("frames_per_launch"):
+                # the counter passes run one pass of 512 frames; bytes scale with the frames of a pass
+                traffic = int(tj[dominant]["hbm_bytes_per_launch"] * frames_per_launch / tj[dominant]["frames_per_launch"])
                 launches_per_pass = tj[dominant].get("launches_per_pass", 1)
+                if tj[dominant]["frames_per_launch"] != frames_per_launch:
+                    traffic_note = ("counter passes ran %d frames per pass; scaled to the %d of this run"
+                                    % (tj[dominant]["frames_per_launch"], int(frames_per_launch)))
         except Exception:
             traffic = None
     valu = None
     spath = os.path.join(ROOT, "profiles", "sq_counters.json")
-    if os.path.exists(spath) and frames_per_launch == 512:
+    if os.path.exists(spath):
         try:
             import csv
             sj = json.load(open(spath))
             if sj.get("source_hash") == src_hash:
                 for r in csv.DictReader(open(os.path.join(ROOT, "profiles", sj["file"]))):
                     if r["kernel"] == KERNEL_OF[dominant].split(" ")[0]:
-                        valu = float(r["SQ_INSTS_VALU"])
+                        valu = float(r["SQ_INSTS_VALU"]) * frames_per_launch / 512.0   # the counter pass ran 512 frames
         except Exception:
             valu = None
     alg = ALG_BYTES[dominant]

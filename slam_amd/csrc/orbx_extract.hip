@@ -2692,16 +2692,8 @@ struct orbx_handle {
     } hostSlots[3];
     hipStream_t copyIn = nullptr, copyOut = nullptr;
     struct CopyPool* pool = nullptr;
-    u8* dImgStage = nullptr;
-    size_t imgStageCap = 0;
-    u8* dRawStage = nullptr;  // host rows as they are (any row stride), before the repack to the staged pitch
-    size_t rawStageCap = 0;
     u8* dAlignStage = nullptr;  // aligned copies of device-resident frames whose layout is not word-aligned (one slice per pass in flight)
     size_t alignStageCap = 0;
-    orbx_keypoint* dKpStage = nullptr;
-    u8* dDescStage = nullptr;
-    int* dNStage = nullptr;
-    size_t outStageCap = 0;
     // last call (for orbx_get_level and the debug taps)
     ImgRef lastImg0 = {nullptr, 0, 0};
     int lastBatch = 0, lastFirstFrame = 0;
@@ -3906,8 +3898,7 @@ void orbx_destroy(orbx_handle* h) {
     if (h->copyOut) (void)hipStreamDestroy(h->copyOut);
     delete h->pool;
     if (h->hErr) (void)hipHostFree(h->hErr);
-    free_dev(h->dTaps); free_dev(h->dWalk); free_dev(h->dCells); free_dev(h->dImgStage); free_dev(h->dRawStage); free_dev(h->dAlignStage); free_dev(h->dKpStage);
-    free_dev(h->dDescStage); free_dev(h->dNStage);
+    free_dev(h->dTaps); free_dev(h->dWalk); free_dev(h->dCells); free_dev(h->dAlignStage);
     for (int s = 0; s < ORBX_STAGE_COUNT; s++)
         for (auto& e : h->prof.ev[s]) {
             (void)hipEventDestroy(e.first);
