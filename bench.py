@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
-    ap.add_argument("--chunk", type=int, default=1024, help="frames per internal pass")
+    ap.add_argument("--chunk", type=int, default=512, help="frames per internal pass")
     ap.add_argument("--cpu-frames", type=int, default=4096, help="sample size of the CPU baseline")
     ap.add_argument("--schedule", choices=["both", "default", "serial"], default="both",
                     help="default: only the timed region (the library's default schedule); both: also a serialised run; "
