@@ -1844,12 +1844,15 @@ __global__ __launch_bounds__(256) void k_records(int pack, int n, orbx_keypoint*
 }
 
 // ------------------------------------------------------------------ stereo
-// Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for a rectified
-// pair.  The reference's per-row candidate lists are replaced by a direct scan:
-// a right keypoint is a candidate of image row v when floor(y - r) <= v <=
-// ceil(y + r), r = 2*scale[octave] (:618-630); scanning right keypoints in index
-// order visits them in the order the row list holds them.
+// Frame::ComputeStereoMatches (reference src/Frame.cc:603-774) for rectified pairs.  As in the
+// reference, every image row has a list of the right keypoints that may match a left keypoint on
+// that row: right keypoint i is in the lists of rows floor(y - r) .. ceil(y + r), r =
+// 2*scale[octave] (:618-630).  The lists are built per pair as a CSR table (counts, prefix sum,
+// fill: the order inside a list is whatever the atomics give, which does not matter because the
+// best candidate is the minimum of (distance, index) keys: the first minimum in index order, as in
+// the reference's scan of a list that holds ascending indices).
 const int MAX_LEVELS = ORBM_MAX_LEVELS;
+const int STEREO_MAX_ROWS = 4096;
 
 struct DevPyramid {
     const u8* ptr[MAX_LEVELS];
@@ -1858,25 +1861,23 @@ struct DevPyramid {
 
 struct StereoParams {
     float scale[MAX_LEVELS], invScale[MAX_LEVELS];
-    int nlevels, nRows;
+    int nlevels;
     float mbf, maxD;
 };
 
-__device__ __forceinline__ void stereo_rows_body(const DevFrame& right, const StereoParams& sp, int4* rows, int i) {
-    if (i >= right.n) return;
-    const orbx_keypoint kp = right.kps[i];
-    int4 o = make_int4(1, 0, kp.octave, __float_as_int(kp.x));  // empty band for an octave outside the pyramid
-    if (kp.octave >= 0 && kp.octave < sp.nlevels) {
-        const float r = 2.0f * sp.scale[kp.octave];
-        o.y = (int)ceilf(kp.y + r);
-        o.x = (int)floorf(kp.y - r);
-    }
-    rows[i] = o;
-}
-
-__global__ void k_stereo_rows(DevFrame right, StereoParams sp, int4* rows) {
-    stereo_rows_body(right, sp, rows, blockIdx.x * blockDim.x + threadIdx.x);
-}
+// One rectified pair.  rows[i] = (first row, last row, octave, x) of right keypoint i (an empty range
+// for an octave outside the pyramid); rowStart[nRows + 1] / rowItems: the per-row lists.
+struct StereoJob {
+    DevFrame left, right;
+    DevPyramid pl, pr;
+    int4* rows;
+    int *rowStart, *rowItems;
+    int* sad;
+    float *uRight, *depth;
+    int* kept;
+    int nRows;
+    int useLists;  // 0: few right keypoints, every left keypoint scans all of them (no lists are built)
+};
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
@@ -1884,12 +1885,85 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
-// One wave per left keypoint: descriptor argmin over the row band, then the 11x11 SAD
+// One workgroup of 1024 threads per pair: row ranges, counts per row, prefix sum, fill.
+__device__ __forceinline__ void stereo_rows_body(const StereoJob& J, const StereoParams& sp) {
+    __shared__ int cnt[STEREO_MAX_ROWS];
+    __shared__ int part[32];
+    const int tid = threadIdx.x, nRows = J.nRows, n = J.right.n;
+    for (int r = tid; r < STEREO_MAX_ROWS; r += 1024) cnt[r] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const orbx_keypoint kp = J.right.kps[i];
+        int4 o = make_int4(1, 0, kp.octave, __float_as_int(kp.x));  // empty range for an octave outside the pyramid
+        if (kp.octave >= 0 && kp.octave < sp.nlevels && kp.y == kp.y) {
+            const float r = 2.0f * sp.scale[kp.octave];
+            // clamped like the reference's "yi >= 0 && yi < nRows"; the float clamp keeps the conversion defined
+            o.y = (int)fminf(ceilf(kp.y + r), (float)(nRows - 1));
+            o.x = (int)fmaxf(floorf(kp.y - r), 0.0f);
+            if (J.useLists)
+                for (int y = o.x; y <= o.y; y++) atomicAdd(&cnt[y], 1);
+        }
+        J.rows[i] = o;
+    }
+    if (!J.useLists) return;  // uniform over the workgroup
+    __syncthreads();
+    // exclusive prefix sum over the rows: four rows per thread, then the threads' totals
+    const int r0 = 4 * tid;
+    const int c0 = cnt[r0], c1 = cnt[r0 + 1], c2 = cnt[r0 + 2], c3 = cnt[r0 + 3];
+    // inclusive scan of the threads' totals: inside each wave by shuffles, then over the 16 wave totals
+    const int mine = c0 + c1 + c2 + c3;
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(inc, d);
+        if ((tid & 63) >= d) inc += v;
+    }
+    if ((tid & 63) == 63) part[tid >> 6] = inc;
+    __syncthreads();
+    if (tid < 16) {
+        int w = part[tid];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int v = __shfl_up(w, d, 16);
+            if (tid >= d) w += v;
+        }
+        part[16 + tid] = w;  // inclusive totals of waves 0 .. tid
+    }
+    __syncthreads();
+    const int waveBase = (tid >> 6) ? part[16 + (tid >> 6) - 1] : 0;
+    const int base = waveBase + inc - mine;
+    cnt[r0] = base;
+    cnt[r0 + 1] = base + c0;
+    cnt[r0 + 2] = base + c0 + c1;
+    cnt[r0 + 3] = base + c0 + c1 + c2;
+    __syncthreads();
+    for (int r = tid; r < nRows; r += 1024) J.rowStart[r] = cnt[r];
+    if (tid == 0) J.rowStart[nRows] = part[16 + 15];
+    __syncthreads();
+    // fill: cnt[row] is now the row's write cursor
+    for (int i = tid; i < n; i += 1024) {
+        const int4 o = J.rows[i];
+        for (int y = o.x; y <= o.y; y++) J.rowItems[atomicAdd(&cnt[y], 1)] = i;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_stereo_rows_jobs(const StereoJob* __restrict__ jobs, StereoParams sp) {
+    stereo_rows_body(jobs[blockIdx.x], sp);
+}
+// (one pair, the record passed as a kernel argument: no upload in front of a call that is all latency)
+__global__ __launch_bounds__(1024) void k_stereo_rows_one(StereoJob J, StereoParams sp) { stereo_rows_body(J, sp); }
+
+// One wave per left keypoint: descriptor argmin over its row's list, then the 11x11 SAD
 // search over 11 column shifts on the keypoint's pyramid level and the parabola fit.
 // sad[iL] receives the best SAD (the key of the later median cut) or -1.
-__device__ __forceinline__ void stereo_match_body(const DevFrame& left, const DevFrame& right, const int4* __restrict__ rows,
-                                                  const DevPyramid& pl, const DevPyramid& pr, const StereoParams& sp,
-                                                  float* uRight, float* depth, int* sad, int iL, int lane) {
+template <bool LISTS>
+__device__ __forceinline__ void stereo_match_body(const StereoJob& J, const StereoParams& sp) {
+    const DevFrame& left = J.left;
+    const DevFrame& right = J.right;
+    const DevPyramid& pl = J.pl;
+    const DevPyramid& pr = J.pr;
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (iL >= left.n) return;
     const orbx_keypoint kpL = left.kps[iL];
     const float uL = kpL.x, vL = kpL.y;
@@ -1898,7 +1972,7 @@ __device__ __forceinline__ void stereo_match_body(const DevFrame& left, const De
     int outS = -1;
     do {
         if (levelL < 0 || levelL >= sp.nlevels) break;
-        if (!(vL >= 0.0f) || !(vL < (float)sp.nRows)) break;
+        if (!(vL >= 0.0f) || !(vL < (float)J.nRows)) break;
         const int row = (int)vL;
         const float minD = 0;
         const float minU = uL - sp.maxD;
@@ -1907,18 +1981,22 @@ __device__ __forceinline__ void stereo_match_body(const DevFrame& left, const De
         const uint4* dl = (const uint4*)(left.desc + (size_t)iL * 32);
         const uint4 a0 = dl[0], a1 = dl[1];
         u64 best = ~0ull;
-        for (int base = 0; base < right.n; base += 64) {
-            const int i = base + lane;
-            if (i < right.n) {
-                const int4 rw = rows[i];
-                const float uR = __int_as_float(rw.w);
-                if (rw.x <= row && row <= rw.y && rw.z >= levelL - 1 && rw.z <= levelL + 1 && uR >= minU && uR <= maxU) {
-                    const uint4* dr = (const uint4*)(right.desc + (size_t)i * 32);
-                    const int d = hamming256(a0, a1, dr[0], dr[1]);
-                    if (d < TH_HIGH) {  // bestDist starts at TH_HIGH, strict < (:650, :672)
-                        const u64 key = ((u64)d << 32) | (u32)i;
-                        best = key < best ? key : best;
-                    }
+        // candidates: the row's list, or (a pair with few right keypoints, for which building the lists would
+        // take longer than it saves) every right keypoint, tested against its row range
+        const int4* __restrict__ rows = J.rows;
+        const int* __restrict__ items = J.rowItems;
+        const u8* __restrict__ rdesc = right.desc;
+        const int b0 = LISTS ? J.rowStart[row] : 0, b1 = LISTS ? J.rowStart[row + 1] : right.n;
+        for (int p = b0 + lane; p < b1; p += 64) {
+            const int i = LISTS ? items[p] : p;
+            const int4 rw = rows[i];
+            const float uR = __int_as_float(rw.w);
+            if ((LISTS || (rw.x <= row && row <= rw.y)) && rw.z >= levelL - 1 && rw.z <= levelL + 1 && uR >= minU && uR <= maxU) {
+                const uint4* dr = (const uint4*)(rdesc + (size_t)i * 32);
+                const int d = hamming256(a0, a1, dr[0], dr[1]);
+                if (d < TH_HIGH) {  // bestDist starts at TH_HIGH, strict < (:650, :672)
+                    const u64 key = ((u64)d << 32) | (u32)i;
+                    best = key < best ? key : best;
                 }
             }
         }
@@ -1994,24 +2072,29 @@ __device__ __forceinline__ void stereo_match_body(const DevFrame& left, const De
         }
     } while (0);
     if (lane == 0) {
-        uRight[iL] = outU;
-        depth[iL] = outD;
-        sad[iL] = outS;
+        J.uRight[iL] = outU;
+        J.depth[iL] = outD;
+        J.sad[iL] = outS;
     }
 }
 
-__global__ __launch_bounds__(256) void k_stereo_match(DevFrame left, DevFrame right, const int4* __restrict__ rows,
-                                                      DevPyramid pl, DevPyramid pr, StereoParams sp, float* uRight,
-                                                      float* depth, int* sad) {
-    stereo_match_body(left, right, rows, pl, pr, sp, uRight, depth, sad, blockIdx.x * 4 + (threadIdx.x >> 6),
-                      threadIdx.x & 63);
+__global__ __launch_bounds__(256) void k_stereo_match_jobs(const StereoJob* __restrict__ jobs, StereoParams sp) {
+    stereo_match_body<true>(jobs[blockIdx.y], sp);
+}
+template <bool LISTS>
+__global__ __launch_bounds__(256) void k_stereo_match_one(StereoJob J, StereoParams sp) {
+    stereo_match_body<LISTS>(J, sp);
 }
 
 // :763-774: median of the accepted SAD distances (element size/2 of the sorted list),
 // then every match with distance >= 1.5*1.4*median is dropped.  SAD <= 121*510, so the
 // median comes from two LDS histogram passes (high bits, then low bits).
-__device__ __forceinline__ void stereo_median_body(int n, const int* __restrict__ sad, float* uRight, float* depth,
-                                                   int* kept) {
+__device__ __forceinline__ void stereo_median_body(const StereoJob& J) {
+    const int n = J.left.n;
+    const int* __restrict__ sad = J.sad;
+    float* uRight = J.uRight;
+    float* depth = J.depth;
+    int* kept = J.kept;
     __shared__ int hist[1024];
     __shared__ int sh[4];
     const int tid = threadIdx.x;
@@ -2082,40 +2165,8 @@ __device__ __forceinline__ void stereo_median_body(int n, const int* __restrict_
         if (tid == 0) *kept = sh[3];
     }
 }
-
-__global__ __launch_bounds__(1024) void k_stereo_median(int n, const int* __restrict__ sad, float* uRight, float* depth,
-                                                        int* kept) {
-    stereo_median_body(n, sad, uRight, depth, kept);
-}
-
-// The same three steps for a table of independent rectified pairs (blockIdx.y / blockIdx.x = pair).
-struct StereoJob {
-    DevFrame left, right;
-    DevPyramid pl, pr;
-    int4* rows;
-    int* sad;
-    float *uRight, *depth;
-    int* kept;
-    int nRows;
-};
-
-__global__ void k_stereo_rows_jobs(const StereoJob* __restrict__ jobs, StereoParams sp) {
-    const StereoJob& J = jobs[blockIdx.y];
-    stereo_rows_body(J.right, sp, J.rows, blockIdx.x * blockDim.x + threadIdx.x);
-}
-
-__global__ __launch_bounds__(256) void k_stereo_match_jobs(const StereoJob* __restrict__ jobs, StereoParams sp) {
-    const StereoJob& J = jobs[blockIdx.y];
-    if ((int)blockIdx.x * 4 >= J.left.n) return;
-    sp.nRows = J.nRows;
-    stereo_match_body(J.left, J.right, J.rows, J.pl, J.pr, sp, J.uRight, J.depth, J.sad,
-                      blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
-}
-
-__global__ __launch_bounds__(1024) void k_stereo_median_jobs(const StereoJob* __restrict__ jobs) {
-    const StereoJob& J = jobs[blockIdx.x];
-    stereo_median_body(J.left.n, J.sad, J.uRight, J.depth, J.kept);
-}
+__global__ __launch_bounds__(1024) void k_stereo_median_jobs(const StereoJob* __restrict__ jobs) { stereo_median_body(jobs[blockIdx.x]); }
+__global__ __launch_bounds__(1024) void k_stereo_median_one(StereoJob J) { stereo_median_body(J); }
 
 // Each thread keeps KNN_QPT query descriptors in registers.  Every thread of the grid walks
 // the same train rows in the same order, so a train descriptor is a wave-uniform value: it is
@@ -2651,7 +2702,7 @@ enum {
     SL_F1_KPS = 0, SL_F1_DESC, SL_F2_KPS, SL_F2_DESC, SL_CELL_START, SL_CELL_ITEMS, SL_CELL_OF, SL_QX, SL_QY,
     SL_QR, SL_QMIN, SL_QMAX, SL_QDESC, SL_COUNTS, SL_OFFS, SL_CAND_IDX, SL_CAND_DIST, SL_STATE_A, SL_STATE_B,
     SL_STATE_C, SL_STATE_D, SL_PREV, SL_SCALAR, SL_VALID, SL_U, SL_V, SL_INVZ, SL_HASOBS, SL_URIGHT, SL_SF,
-    SL_KNN_Q, SL_KNN_T, SL_KNN_I, SL_KNN_D, SL_KNN_S, SL_KNN_I2, SL_KNN_D2, SL_KNN_S2, SL_ST_ROWS, SL_ST_SAD,
+    SL_KNN_Q, SL_KNN_T, SL_KNN_I, SL_KNN_D, SL_KNN_S, SL_KNN_I2, SL_KNN_D2, SL_KNN_S2, SL_ST_ROWS, SL_ST_SAD, SL_ST_START, SL_ST_ITEMS,
     SL_ST_U, SL_ST_D, SL_FV1_NODES, SL_FV1_START, SL_FV1_ITEMS, SL_FV2_NODES, SL_FV2_START, SL_FV2_ITEMS, SL_BW_VALID1,
     SL_BW_VALID2, SL_BW_M12, SL_BW_M21, SL_BW_BIN, SL_BW_HIST, SL_BW_UR1, SL_BW_UR2, SL_WB_LEVEL, SL_WB_IDX, SL_WB_DIST,
     SL_WB_QUR, SL_WB_IDX2, SL_WB_DIST2, SL_DD_DESC, SL_DD_START, SL_DD_BEST, SL_DD_MED, SL_DD_OUT,
@@ -3714,6 +3765,40 @@ static int fill_pyramid(const orbm_pyramid* p, DevPyramid* d, const char* which)
     return ORBX_OK;
 }
 
+// The three launches of the stereo step for a table of pairs already in device memory.
+static int run_stereo_jobs(orbm_context* m, const StereoJob* dJobs, int njobs, int maxL, const StereoParams& sp) {
+    ORBM_LAUNCH(k_stereo_rows_jobs, dim3(njobs), dim3(1024), 0, m->stream, dJobs, sp);
+    ORBX_HIP_CHECK(hipGetLastError());
+    if (maxL) {
+        ORBM_LAUNCH(k_stereo_match_jobs, dim3((maxL + 3) / 4, njobs), dim3(256), 0, m->stream, dJobs, sp);
+        ORBX_HIP_CHECK(hipGetLastError());
+    }
+    ORBM_LAUNCH(k_stereo_median_jobs, dim3(njobs), dim3(1024), 0, m->stream, dJobs);
+    ORBX_HIP_CHECK(hipGetLastError());
+    return ORBX_OK;
+}
+
+static int stereo_params(const float* scale_factors, const float* inv_scale_factors, int nlevels, float mb, float mbf,
+                         StereoParams* sp, int* bandMax) {
+    memset(sp, 0, sizeof(*sp));
+    sp->nlevels = nlevels;
+    float smax = 1.0f;
+    for (int l = 0; l < nlevels; l++) {
+        sp->scale[l] = scale_factors[l];
+        sp->invScale[l] = inv_scale_factors[l];
+        if (scale_factors[l] > smax) smax = scale_factors[l];
+    }
+    if (!(smax < 1000.0f)) {
+        orbx_set_error("scale factors out of range");
+        return ORBX_ERR_INVALID;
+    }
+    sp->mbf = mbf;
+    sp->maxD = mbf / mb;  // minZ = mb, reference src/Frame.cc:633-636
+    // rows a right keypoint can be listed on: ceil(y + r) - floor(y - r) + 1 <= 2 r + 3 with r = 2 * scale
+    *bandMax = (int)(4.0f * smax) + 4;
+    return ORBX_OK;
+}
+
 int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const orbm_frame* right,
                                 const orbm_pyramid* pyr_left, const orbm_pyramid* pyr_right, const float* scale_factors,
                                 const float* inv_scale_factors, float mb, float mbf, float* u_right, float* depth,
@@ -3724,48 +3809,49 @@ int orbm_compute_stereo_matches(orbm_context* m, const orbm_frame* left, const o
         orbx_set_error("invalid argument");
         return ORBX_ERR_INVALID;
     }
-    DevPyramid pl, pr;
-    if ((rc = fill_pyramid(pyr_left, &pl, "left"))) return rc;
-    if ((rc = fill_pyramid(pyr_right, &pr, "right"))) return rc;
+    StereoJob J;
+    memset(&J, 0, sizeof(J));
+    if ((rc = fill_pyramid(pyr_left, &J.pl, "left"))) return rc;
+    if ((rc = fill_pyramid(pyr_right, &J.pr, "right"))) return rc;
     if (pyr_left->nlevels != pyr_right->nlevels) {
         orbx_set_error("left and right pyramids differ in depth");
         return ORBX_ERR_INVALID;
     }
-    DevFrame dl, dr;
-    if ((rc = make_frame(m, left, SL_F1_KPS, SL_F1_DESC, mem_space, &dl))) return rc;
-    if ((rc = make_frame(m, right, SL_F2_KPS, SL_F2_DESC, mem_space, &dr))) return rc;
+    if ((rc = make_frame(m, left, SL_F1_KPS, SL_F1_DESC, mem_space, &J.left))) return rc;
+    if ((rc = make_frame(m, right, SL_F2_KPS, SL_F2_DESC, mem_space, &J.right))) return rc;
     if (n_stereo) *n_stereo = 0;
-    if (dl.n == 0) return ORBX_OK;
+    if (J.left.n == 0) return ORBX_OK;
     StereoParams sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.nlevels = pyr_left->nlevels;
-    for (int l = 0; l < sp.nlevels; l++) {
-        sp.scale[l] = scale_factors[l];
-        sp.invScale[l] = inv_scale_factors[l];
+    int bandMax;
+    if ((rc = stereo_params(scale_factors, inv_scale_factors, pyr_left->nlevels, mb, mbf, &sp, &bandMax))) return rc;
+    J.nRows = J.pl.h[0];  // reference src/Frame.cc:610
+    if (J.nRows > STEREO_MAX_ROWS) {
+        orbx_set_error("stereo: images of more than %d rows are not supported", STEREO_MAX_ROWS);
+        return ORBX_ERR_UNSUPPORTED;
     }
-    sp.nRows = pl.h[0];  // reference src/Frame.cc:610
-    sp.mbf = mbf;
-    // reference src/Frame.cc:633-636
-    const float minZ = mb;
-    sp.maxD = mbf / minZ;
-    void *dRows, *dSad, *dKept;
-    if ((rc = pool_get(m, SL_ST_ROWS, (size_t)std::max(dr.n, 1) * sizeof(int4), &dRows))) return rc;
-    if ((rc = pool_get(m, SL_ST_SAD, (size_t)dl.n * sizeof(int), &dSad))) return rc;
-    if ((rc = pool_get(m, SL_SCALAR, 64, &dKept))) return rc;
-    float *dU, *dD;
-    if ((rc = stage_out(m, SL_ST_U, u_right, (size_t)dl.n, mem_space, &dU))) return rc;
-    if ((rc = stage_out(m, SL_ST_D, depth, (size_t)dl.n, mem_space, &dD))) return rc;
-    if (dr.n) {
-        ORBM_LAUNCH(k_stereo_rows, dim3((dr.n + 255) / 256), dim3(256), 0, m->stream, dr, sp, (int4*)dRows);
-        ORBX_HIP_CHECK(hipGetLastError());
-    }
-    ORBM_LAUNCH(k_stereo_match, dim3((dl.n + 3) / 4), dim3(256), 0, m->stream, dl, dr, (const int4*)dRows, pl, pr, sp,
-                       dU, dD, (int*)dSad);
+    void *dRows, *dSad, *dKept, *dStart, *dItems;
+    if ((rc = pool_get(m, SL_ST_ROWS, (size_t)std::max(J.right.n, 1) * sizeof(int4), &dRows)) ||
+        (rc = pool_get(m, SL_ST_SAD, (size_t)J.left.n * sizeof(int), &dSad)) || (rc = pool_get(m, SL_SCALAR, 64, &dKept)) ||
+        (rc = pool_get(m, SL_ST_START, (size_t)(J.nRows + 1) * sizeof(int), &dStart)) ||
+        (rc = pool_get(m, SL_ST_ITEMS, (size_t)std::max(J.right.n, 1) * bandMax * sizeof(int), &dItems)))
+        return rc;
+    if ((rc = stage_out(m, SL_ST_U, u_right, (size_t)J.left.n, mem_space, &J.uRight))) return rc;
+    if ((rc = stage_out(m, SL_ST_D, depth, (size_t)J.left.n, mem_space, &J.depth))) return rc;
+    J.rows = (int4*)dRows;
+    J.rowStart = (int*)dStart;
+    J.rowItems = (int*)dItems;
+    J.sad = (int*)dSad;
+    J.kept = (int*)dKept;
+    J.useLists = J.right.n > 1536;  // one pair per call is a latency path: below that the direct scan is faster than the set-up of the lists
+    ORBM_LAUNCH(k_stereo_rows_one, dim3(1), dim3(1024), 0, m->stream, J, sp);
+    if (J.useLists)
+        ORBM_LAUNCH(k_stereo_match_one<true>, dim3((J.left.n + 3) / 4, 1), dim3(256), 0, m->stream, J, sp);
+    else
+        ORBM_LAUNCH(k_stereo_match_one<false>, dim3((J.left.n + 3) / 4, 1), dim3(256), 0, m->stream, J, sp);
+    ORBM_LAUNCH(k_stereo_median_one, dim3(1), dim3(1024), 0, m->stream, J);
     ORBX_HIP_CHECK(hipGetLastError());
-    ORBM_LAUNCH(k_stereo_median, dim3(1), dim3(1024), 0, m->stream, dl.n, (const int*)dSad, dU, dD, (int*)dKept);
-    ORBX_HIP_CHECK(hipGetLastError());
-    if ((rc = copy_back(m, u_right, (const float*)dU, (size_t)dl.n, mem_space))) return rc;
-    if ((rc = copy_back(m, depth, (const float*)dD, (size_t)dl.n, mem_space))) return rc;
+    if ((rc = copy_back(m, u_right, (const float*)J.uRight, (size_t)J.left.n, mem_space))) return rc;
+    if ((rc = copy_back(m, depth, (const float*)J.depth, (size_t)J.left.n, mem_space))) return rc;
     if (n_stereo && (rc = d2h(m, n_stereo, dKept, sizeof(int)))) return rc;
     if (mem_space == ORBX_MEM_HOST || n_stereo) ORBX_HIP_CHECK(sync_deliver(m));
     return ORBX_OK;
@@ -3780,29 +3866,35 @@ int orbm_compute_stereo_matches_batch(orbm_context* m, orbm_stereo_job* jobsIn, 
         return ORBX_ERR_INVALID;
     }
     if (njobs == 0) return ORBX_OK;
-    size_t rowsTotal = 0, sadTotal = 0;
-    int maxL = 0, maxR = 0;
+    StereoParams sp;
+    int bandMax;
+    if ((rc = stereo_params(scale_factors, inv_scale_factors, nlevels, mb, mbf, &sp, &bandMax))) return rc;
+    size_t rowsTotal = 0, sadTotal = 0, startTotal = 0;
+    int maxL = 0;
     for (int i = 0; i < njobs; i++) {
         const orbm_stereo_job& P = jobsIn[i];
         if (P.left.n < 0 || P.right.n < 0 || P.left.n > 65000 || P.right.n > 65000 ||
-            (P.left.n > 0 && (!P.u_right || !P.depth)) || P.pyr_left.nlevels != nlevels || P.pyr_right.nlevels != nlevels) {
+            (P.left.n > 0 && (!P.u_right || !P.depth)) || P.pyr_left.nlevels != nlevels || P.pyr_right.nlevels != nlevels ||
+            P.pyr_left.height[0] < 1 || P.pyr_left.height[0] > STEREO_MAX_ROWS) {
             orbx_set_error("stereo job %d: invalid argument", i);
             return ORBX_ERR_INVALID;
         }
         rowsTotal += (size_t)P.right.n;
         sadTotal += (size_t)P.left.n;
+        startTotal += (size_t)P.pyr_left.height[0] + 1;
         maxL = std::max(maxL, P.left.n);
-        maxR = std::max(maxR, P.right.n);
     }
-    void *dJobs, *dRows, *dSad, *dKept;
+    void *dJobs, *dRows, *dSad, *dKept, *dStart, *dItems;
     if ((rc = pool_get(m, SL_JB_JOBS, (size_t)njobs * sizeof(StereoJob), &dJobs)) ||
         (rc = pool_get(m, SL_ST_ROWS, std::max(rowsTotal, (size_t)1) * sizeof(int4), &dRows)) ||
         (rc = pool_get(m, SL_ST_SAD, std::max(sadTotal, (size_t)1) * sizeof(int), &dSad)) ||
-        (rc = pool_get(m, SL_JB_TOT, (size_t)njobs * sizeof(int), &dKept)))
+        (rc = pool_get(m, SL_JB_TOT, (size_t)njobs * sizeof(int), &dKept)) ||
+        (rc = pool_get(m, SL_ST_START, startTotal * sizeof(int), &dStart)) ||
+        (rc = pool_get(m, SL_ST_ITEMS, std::max(rowsTotal, (size_t)1) * bandMax * sizeof(int), &dItems)))
         return rc;
     StereoJob* jobs = (StereoJob*)arena_alloc(m, (size_t)njobs * sizeof(StereoJob));
     if (!jobs) return ORBX_ERR_HIP;
-    size_t ro = 0, so = 0;
+    size_t ro = 0, so = 0, sto = 0;
     for (int i = 0; i < njobs; i++) {
         const orbm_stereo_job& P = jobsIn[i];
         StereoJob& J = jobs[i];
@@ -3811,35 +3903,21 @@ int orbm_compute_stereo_matches_batch(orbm_context* m, orbm_stereo_job* jobsIn, 
         if ((rc = fill_pyramid(&P.pyr_right, &J.pr, "right"))) return rc;
         if ((rc = make_frame(m, &P.left, 0, 0, ORBX_MEM_DEVICE, &J.left))) return rc;
         if ((rc = make_frame(m, &P.right, 0, 0, ORBX_MEM_DEVICE, &J.right))) return rc;
+        J.nRows = J.pl.h[0];  // reference src/Frame.cc:610
         J.rows = (int4*)dRows + ro;
+        J.rowStart = (int*)dStart + sto;
+        J.rowItems = (int*)dItems + ro * (size_t)bandMax;
         J.sad = (int*)dSad + so;
         J.uRight = P.u_right;
         J.depth = P.depth;
         J.kept = (int*)dKept + i;
-        J.nRows = J.pl.h[0];  // reference src/Frame.cc:610
+        J.useLists = 1;
         ro += (size_t)P.right.n;
         so += (size_t)P.left.n;
+        sto += (size_t)J.nRows + 1;
     }
     ORBX_HIP_CHECK(hipMemcpyAsync(dJobs, jobs, (size_t)njobs * sizeof(StereoJob), hipMemcpyHostToDevice, m->stream));
-    StereoParams sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.nlevels = nlevels;
-    for (int l = 0; l < nlevels; l++) {
-        sp.scale[l] = scale_factors[l];
-        sp.invScale[l] = inv_scale_factors[l];
-    }
-    sp.mbf = mbf;
-    sp.maxD = mbf / mb;  // reference src/Frame.cc:633-636
-    if (maxR) {
-        ORBM_LAUNCH(k_stereo_rows_jobs, dim3((maxR + 255) / 256, njobs), dim3(256), 0, m->stream, (const StereoJob*)dJobs, sp);
-        ORBX_HIP_CHECK(hipGetLastError());
-    }
-    if (maxL) {
-        ORBM_LAUNCH(k_stereo_match_jobs, dim3((maxL + 3) / 4, njobs), dim3(256), 0, m->stream, (const StereoJob*)dJobs, sp);
-        ORBX_HIP_CHECK(hipGetLastError());
-    }
-    ORBM_LAUNCH(k_stereo_median_jobs, dim3(njobs), dim3(1024), 0, m->stream, (const StereoJob*)dJobs);
-    ORBX_HIP_CHECK(hipGetLastError());
+    if ((rc = run_stereo_jobs(m, (const StereoJob*)dJobs, njobs, maxL, sp))) return rc;
     if ((int)m->totalsHost.size() < njobs) m->totalsHost.resize(njobs);
     if ((rc = d2h(m, m->totalsHost.data(), dKept, (size_t)njobs * sizeof(int)))) return rc;
     ORBX_HIP_CHECK(sync_deliver(m));
