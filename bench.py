@@ -530,7 +530,7 @@ def main():
             dd = d_desc[:HB * cap * 32].cpu().numpy().reshape(HB, cap, 32)
             same = bool(np.array_equal(dn, h_n)) and all(
                 dk[f, :dn[f]].tobytes() == h_k[f, :dn[f]].tobytes() and np.array_equal(dd[f, :dn[f]], h_d[f, :dn[f]]) for f in range(HB))
-            out["host_path"] = {"frames_per_s": round(HB * reps / dt, 1), "frames_per_call": HB, "frames_per_pass": ex.max_batch,
+            out["host_path"] = {"frames_per_s": round(HB * reps / dt, 1), "frames_per_call": HB, "frames_per_pass": min(ex.max_batch, 128),
                                 "bytes_in_per_frame": W * H, "bytes_out_per_frame": cap * 60 + 4,
                                 "identical_to_device_resident_outputs": same,
                                 "note": "pageable host images in, host keypoints / descriptors out (orbx_extract_batch, ORBX_MEM_HOST): "

@@ -4023,8 +4023,12 @@ int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh
             ORBX_HIP_CHECK(hipStreamWaitEvent(h->pipes[p].st, h->evStart, 0));
         }
     }
-    if (mem_space == ORBX_MEM_HOST)
-        return extract_host_pipelined(h, imgs, B, w, hh, row_stride, img_stride, kps, desc, cap, n_out, chunk);
+    if (mem_space == ORBX_MEM_HOST) {
+        // the transfers, not the kernels, bound this path: shorter passes (128 frames of 640x480 still keep the
+        // kernels far ahead of the link) fill and drain the ring of slots sooner
+        static const int hostPass = getenv("ORBX_HOST_PASS") ? std::max(atoi(getenv("ORBX_HOST_PASS")), 1) : 128;
+        return extract_host_pipelined(h, imgs, B, w, hh, row_stride, img_stride, kps, desc, cap, n_out, std::min(chunk, hostPass));
+    }
     // Device-resident frames whose layout is not word-aligned are repacked pass by pass (ORBX_NO_REPACK=1
     // keeps the unaligned forms of the kernels, which the tests compare with the repacked path).
     const bool repackDevice = mem_space == ORBX_MEM_DEVICE && !h->noRepack && hh <= 65535 && chunk <= 65535 &&
