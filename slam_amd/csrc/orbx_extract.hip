@@ -285,16 +285,20 @@ __global__ __launch_bounds__(256) void k_resize_stream(ImgRef src, int maxWord, 
 // they live in scalar registers, the row tables come through the scalar cache, and a row's address
 // is a buffer descriptor (scalar) + a scalar row offset + a per-lane 32-bit offset fixed at
 // start-up, so neither the loads nor the stores need address arithmetic.  The vector ALU is left
-// with the arithmetic: per source row one 8-byte load, 4 v_perm, 4 v_dot2, 4 shifts; per
+// with the arithmetic: per source row one 12-byte load, 2 v_alignbyte, 4 v_perm, 4 v_dot2, 4 shifts; per
 // destination row 8 v_mul_hi, the adds, shifts and the byte pack.
 //
-// The lane's taps lie within 8 bytes of its first tap, so one unaligned 8-byte load per source row
-// brings its whole window (the memory pipeline, not the ALU, bounds this kernel: three aligned word
-// loads per row cost a quarter more time than this one).  The window is pulled back from the
-// row's end so that it never reaches past the last pixel of the image.
+// The lane's taps lie within 8 bytes of its first tap.  A source row of its window is one 12-byte load
+// that starts on a word of the row, and a byte shift (v_alignbyte, 2 per row) moves the 8 bytes the
+// selectors address to the front: the memory pipeline, not the ALU, bounds this kernel, and it takes a
+// wave's unaligned 8-byte loads (a lane's window starts every 4.8 bytes) at about half the rate of
+// aligned ones (640x480: 0.47 -> 0.40 us per frame; three aligned word loads per row cost a quarter more
+// time than the unaligned load).  The first tap is pulled back from the row's end so that the 8 bytes
+// never reach past the last pixel of the image.
 struct ResizeLane {
     u32 sel[4], coef[4];
     u32 offS, offD;
+    u32 shift;  // bytes between the aligned 12-byte window that is loaded and the 8 bytes the selectors address
 };
 __device__ __forceinline__ ResizeLane resize_lane(const ResizeTap* __restrict__ xt, int gx, int dw, int sw, u32 srcLaneBase,
                                                   u32 dstLaneBase) {
@@ -309,7 +313,11 @@ __device__ __forceinline__ ResizeLane resize_lane(const ResizeTap* __restrict__ 
         L.sel[j] = d0 | (12u << 8) | (d1 << 16) | (12u << 24);
         L.coef[j] = (u32)(u16)t.c0 | ((u32)(u16)t.c1 << 16);
     }
-    L.offS = srcLaneBase + (u32)start;
+    // the window that is loaded starts on a word of the row when that keeps its 12 bytes inside the row,
+    // and at the first tap otherwise (the last lanes of a row; their third word is never selected)
+    const int first = (start & ~3) + 12 <= sw ? (start & ~3) : start;
+    L.offS = srcLaneBase + (u32)first;
+    L.shift = (u32)(start - first);
     L.offD = dstLaneBase + 4u * (u32)gx;
     return L;
 }
@@ -318,16 +326,16 @@ __device__ __forceinline__ ResizeLane resize_lane(const ResizeTap* __restrict__ 
 __device__ __forceinline__ void resize_walk(const ResizeLane& L, const __amdgpu_buffer_rsrc_t srcRs,
                                             const __amdgpu_buffer_rsrc_t dstRs, int srcPitch, int dPitch, int sh,
                                             const ResizeTap* __restrict__ yt, const ResizeTap* __restrict__ st, int y0, int y1) {
-    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    typedef u32 u32x3 __attribute__((ext_vector_type(3)));
     struct Group {
-        u32x2 raw[RESIZE_PF];
+        u32x3 raw[RESIZE_PF];
         uint4 tab[RESIZE_PF];  // scalar: st[2 s], st[2 s + 1]
     };
     auto load_group = [&](Group& g, int s0) {
 #pragma unroll
         for (int k = 0; k < RESIZE_PF; k++) {
             const int sr = min(s0 + k, sh - 1);
-            g.raw[k] = __builtin_amdgcn_raw_buffer_load_b64(srcRs, (int)L.offS, sr * srcPitch, 0);
+            g.raw[k] = __builtin_amdgcn_raw_buffer_load_b96(srcRs, (int)L.offS, sr * srcPitch, 0);
             g.tab[k] = load_table<uint4>(st + 2 * sr);
         }
     };
@@ -345,7 +353,8 @@ __device__ __forceinline__ void resize_walk(const ResizeLane& L, const __amdgpu_
     auto run_group = [&](const Group& g, int s0) {
 #pragma unroll
         for (int k = 0; k < RESIZE_PF; k++) {
-            const u32 W0 = g.raw[k][0], W1 = g.raw[k][1];
+            const u32 W0 = __builtin_amdgcn_alignbyte(g.raw[k][1], g.raw[k][0], L.shift);
+            const u32 W1 = __builtin_amdgcn_alignbyte(g.raw[k][2], g.raw[k][1], L.shift);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const u32 pr = __builtin_amdgcn_perm(W1, W0, L.sel[j]);
@@ -444,6 +453,11 @@ struct PyramidArgs {
     PyramidLevel lv[ORBX_MAX_LEVELS];
 };
 #define PYR_WAVES 16
+#ifdef ORBX_PYR_DIAG
+// Diagnostic build only (tools/probe/pyr_phases.py): per frame, wave and level three s_memtime stamps
+// (level start, walk done, barrier passed).
+__device__ unsigned long long* d_pyrDiag;
+#endif
 #define PYR_STRIP_MAX 16  // widest remainder (column groups) that is done as a block of rows instead of a chunk of walks
 __global__ __launch_bounds__(64 * PYR_WAVES, 8) void k_pyramid_frame(ImgRef img0, u8* pyr, i64 pyrFrameBytes, int imgBytes,
                                                                      PyramidArgs args, int nlevels) {
@@ -462,6 +476,10 @@ __global__ __launch_bounds__(64 * PYR_WAVES, 8) void k_pyramid_frame(ImgRef img0
     ResizeLane L = lane_setup(1);
     for (int l = 1; l < nlevels; l++) {
         const PyramidLevel& A = args.lv[l];
+#ifdef ORBX_PYR_DIAG
+        unsigned long long* drec = d_pyrDiag ? d_pyrDiag + (((size_t)f * PYR_WAVES + wave) * ORBX_MAX_LEVELS + l) * 4 : nullptr;
+        if (drec && lane == 0) drec[0] = __builtin_amdgcn_s_memtime();
+#endif
         const __amdgpu_buffer_rsrc_t srcRs =
             l == 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)(img0.base + (i64)f * img0.frameStride), 0, imgBytes, 0x00020000)
                    : __builtin_amdgcn_make_buffer_rsrc((void*)(frame + A.srcOff), 0, (int)(A.sh * A.srcPitch), 0x00020000);
@@ -488,9 +506,11 @@ __global__ __launch_bounds__(64 * PYR_WAVES, 8) void k_pyramid_frame(ImgRef img0
                     const int y = stp * R + r;
                     if (y < A.dh) {
                         const ResizeTap ty = A.yt[y];
-                        typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-                        const u32x2 r0 = __builtin_amdgcn_raw_buffer_load_b64(srcRs, (int)(S.offS + (u32)ty.i0 * (u32)A.srcPitch), 0, 0);
-                        const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(srcRs, (int)(S.offS + (u32)ty.i1 * (u32)A.srcPitch), 0, 0);
+                        typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+                        const u32x3 a0 = __builtin_amdgcn_raw_buffer_load_b96(srcRs, (int)(S.offS + (u32)ty.i0 * (u32)A.srcPitch), 0, 0);
+                        const u32x3 a1 = __builtin_amdgcn_raw_buffer_load_b96(srcRs, (int)(S.offS + (u32)ty.i1 * (u32)A.srcPitch), 0, 0);
+                        const u32 r0[2] = {__builtin_amdgcn_alignbyte(a0[1], a0[0], S.shift), __builtin_amdgcn_alignbyte(a0[2], a0[1], S.shift)};
+                        const u32 r1[2] = {__builtin_amdgcn_alignbyte(a1[1], a1[0], S.shift), __builtin_amdgcn_alignbyte(a1[2], a1[1], S.shift)};
                         const u32 b0 = (u32)(u16)ty.c0 << 16, b1 = (u32)(u16)ty.c1 << 16;
                         u32 out = 0;
 #pragma unroll
@@ -506,7 +526,13 @@ __global__ __launch_bounds__(64 * PYR_WAVES, 8) void k_pyramid_frame(ImgRef img0
         }
         // the next level's column taps do not depend on this level's pixels: fetched while the frame's other waves finish
         if (l + 1 < nlevels) L = lane_setup(l + 1);
+#ifdef ORBX_PYR_DIAG
+        if (drec && lane == 0) drec[1] = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();  // waits for this wave's stores, then for every wave of the frame
+#ifdef ORBX_PYR_DIAG
+        if (drec && lane == 0) drec[2] = __builtin_amdgcn_s_memtime();
+#endif
     }
 }
 
@@ -4291,6 +4317,16 @@ int orbx_debug_selected(orbx_handle* h, int frame, int level, int* xs, int* ys, 
     *n = cnt;
     return ORBX_OK;
 }
+
+#ifdef ORBX_PYR_DIAG
+// Diagnostic build only: points the k_pyramid_frame stamps at a caller's device buffer of
+// frames * 16 * ORBX_MAX_LEVELS * 4 64-bit words (NULL turns them off).
+int orbx_debug_pyr_diag(unsigned long long* dev_buf) {
+    ORBX_HIP_CHECK(hipDeviceSynchronize());
+    ORBX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(d_pyrDiag), &dev_buf, sizeof(dev_buf)));
+    return ORBX_OK;
+}
+#endif
 
 #ifdef ORBX_FAST_DIAG
 // Diagnostic build only: points the k_fast phase records at a caller's device buffer of
