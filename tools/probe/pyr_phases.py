@@ -49,7 +49,7 @@ t0 = r[:, :, 0, 0].min(axis=1)                            # a workgroup's first 
 walk = r[..., 1] - r[..., 0]
 wait = r[..., 2] - r[..., 1]
 lvl = r[:, :, :, 2].max(axis=1) - r[:, :, :, 0].min(axis=1)   # level duration per workgroup
-TICK = 0.01  # microseconds per s_memtime tick
+TICK = 0.01  # s_memtime ticks are shown in units of 100
 out = {"frames": a.frames,
        "workgroup_us_mean": round(float((r[:, :, -1, 2].max(axis=1) - t0).mean() * TICK), 2),
        "kernel_span_us": round(float((r[..., 2].max() - r[..., 0].min()) * TICK), 2),
@@ -58,5 +58,8 @@ out = {"frames": a.frames,
        "walk_us_mean_wave": [round(float(x) * TICK, 2) for x in walk.mean(axis=(0, 1))],
        "walk_us_slowest_wave": [round(float(x) * TICK, 2) for x in walk.max(axis=1).mean(axis=0)],
        "walk_us_fastest_wave": [round(float(x) * TICK, 2) for x in walk.min(axis=1).mean(axis=0)],
+       "walk_level1_by_wave": [round(float(x) * TICK, 1) for x in walk[:, :, 0].mean(axis=0)],
+       "walk_level2_by_wave": [round(float(x) * TICK, 1) for x in walk[:, :, 1].mean(axis=0)],
+       "walk_level4_by_wave": [round(float(x) * TICK, 1) for x in walk[:, :, 3].mean(axis=0)],
        "barrier_wait_us_mean_wave": [round(float(x) * TICK, 2) for x in wait.mean(axis=(0, 1))]}
 print(json.dumps(out))
