@@ -115,8 +115,11 @@ int orbx_extract(orbx_handle* h, const uint8_t* img, int w, int h_, size_t strid
 
 /* Batched form: B frames of equal size.  Frame f starts at imgs + f*img_stride.
  * Outputs for frame f start at kps + f*cap_per_frame and desc + f*cap_per_frame*32;
- * n_out[f] receives its keypoint count.  mem_space applies to imgs, kps, desc
- * and n_out alike.  With ORBX_MEM_DEVICE the call only enqueues work on the
+ * n_out[f] receives its keypoint count; what entries n_out[f] .. cap_per_frame - 1 of a frame hold
+ * afterwards is unspecified.  mem_space applies to imgs, kps, desc and n_out alike.  Host-space calls
+ * return when every output has arrived: the frames go through the GPU in passes whose uploads, kernels
+ * and downloads overlap (rows of any stride; buffers that are already page-locked are copied from and
+ * to directly).  With ORBX_MEM_DEVICE the call only enqueues work on the
  * handle's stream; capacity errors found by its kernels are reported by the next
  * orbx_synchronize (or the next host-space call). */
 int orbx_extract_batch(orbx_handle* h, const uint8_t* imgs, int B, int w, int h_,

@@ -22,6 +22,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/orbx_pattern_31.h"
@@ -1735,6 +1736,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* wsumBoth,
     return base + inc - v;
 }
 
+#define QT_KPT 8  // keys per thread that a level may hold in registers
+
 struct QtShared {
     int n, L, prevL, tnew, ncut, nproc, toExpand, done, careful, C;
     int wsum[32];
@@ -1803,18 +1806,17 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     u32* selOut = sel + (i64)f * g.totalSel + LG.selBase;
 
     // LDS carve-up (all arrays have lcap entries unless noted)
-    short4* box[2];
-    u32* cnt[2];
-    u32* seq[2];
+    // (the two copies of a table are named, not an array of pointers indexed by the pass: the compiler
+    // then sees that they point into the LDS and reads them with LDS instructions instead of flat ones)
     unsigned char* p = smemLds;
     if (GTAB) p = nodeTables + ((size_t)f * g.nlevels + l) * nodeTableStride;
-    box[0] = (short4*)p; p += (size_t)lcap * 8;
-    box[1] = (short4*)p; p += (size_t)lcap * 8;
+    short4* const box0 = (short4*)p; p += (size_t)lcap * 8;
+    short4* const box1 = (short4*)p; p += (size_t)lcap * 8;
     u32* childCnt = (u32*)p; p += (size_t)lcap * 16;  // 4 per node; reused as u64 best[]
-    cnt[0] = (u32*)p; p += (size_t)lcap * 4;
-    cnt[1] = (u32*)p; p += (size_t)lcap * 4;
-    seq[0] = (u32*)p; p += (size_t)lcap * 4;
-    seq[1] = (u32*)p; p += (size_t)lcap * 4;
+    u32* const cnt0 = (u32*)p; p += (size_t)lcap * 4;
+    u32* const cnt1 = (u32*)p; p += (size_t)lcap * 4;
+    u32* const seq0 = (u32*)p; p += (size_t)lcap * 4;
+    u32* const seq1 = (u32*)p; p += (size_t)lcap * 4;
     u32* gpre = (u32*)p; p += (size_t)lcap * 4;     // by rank: exclusive prefix of children
     u16* newId = (u16*)p; p += (size_t)lcap * 8;    // 4 per node: list position of each child
     u16* moved = (u16*)p; p += (size_t)lcap * 2;    // new position of a node that stays
@@ -1834,7 +1836,18 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         const int cN = c < LG.nCells ? (int)cc[c] : 0;
         int tot;
         const int off = block_excl_scan<QT_THREADS>(cN, &tot, S.wsum, scanPhase);
-        for (int k = 0; k < cN; k++) kp[nkeys + off + k] = sl[(i64)c * LG.cellCap + k];
+        // eight entries of the cell per trip, their loads issued together (a cell holds 6 on average: one
+        // wait for memory instead of one per entry)
+        const u32* cs = sl + (i64)c * LG.cellCap;
+        u32* cd = kp + nkeys + off;
+        for (int k0 = 0; k0 < cN; k0 += 8) {
+            u32 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = cs[min(k0 + i, cN - 1)];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (k0 + i < cN) cd[k0 + i] = v[i];
+        }
         nkeys += tot;
     }
     __syncthreads();
@@ -1843,28 +1856,58 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         if (tid == 0) *selCnt = 0;
         return;
     }
+    // Levels with at most QT_KPT keys per thread (every level of a 640x480 frame) keep a thread's keys and
+    // their nodes in registers for the whole subdivision: the passes below then touch no global memory,
+    // where each of them paid a round trip for the keys and another for the node numbers.  Key j of thread
+    // tid is key tid + j * QT_THREADS of the level.  Larger levels keep both arrays in global memory.
+    // Both forms are instances of the code below (REG: a compile-time constant inside it).
+    auto subdivide = [&](auto regTag) {
+    constexpr bool REG = decltype(regTag)::value;
+    u32 rkey[REG ? QT_KPT : 1], rnode[REG ? QT_KPT : 1];
+    if constexpr (REG) {
+#pragma unroll
+        for (int j = 0; j < QT_KPT; j++) {
+            rkey[j] = kp[min(tid + j * QT_THREADS, nkeys - 1)];
+            rnode[j] = 0;
+        }
+    }
 
     // ---- roots (reference :545-587)
     const int nIni = LG.nIni;
     const float hX = LG.hX;
     const int ySpan = LG.h - 2 * MIN_BORDER;
-    for (int i = tid; i < lcap; i += QT_THREADS) cnt[0][i] = 0;
+    for (int i = tid; i < lcap; i += QT_THREADS) cnt0[i] = 0;
     __syncthreads();
     // With one or two initial nodes (the usual aspect ratios) every key of a wave would hit the same one
     // or two LDS counters: the wave counts its keys per node with ballots and adds once per node.
     const bool fewRoots = nIni <= 2;
-    for (int k0 = 0; k0 < nkeys; k0 += QT_THREADS) {
-        const int k = k0 + tid;
-        const int r = k < nkeys ? (int)((float)ORBX_PX(kp[k]) / hX) : -1;
-        if (k < nkeys) kn[k] = (u16)r;
+    auto count_root = [&](int r) {  // r = -1: no key; called by every thread of a wave together
         if (fewRoots) {
             const u64 m0 = __ballot(r == 0), m1 = __ballot(r == 1);
             if ((tid & 63) == 0) {
-                if (m0) atomicAdd(&cnt[0][0], (u32)__popcll(m0));
-                if (m1) atomicAdd(&cnt[0][1], (u32)__popcll(m1));
+                if (m0) atomicAdd(&cnt0[0], (u32)__popcll(m0));
+                if (m1) atomicAdd(&cnt0[1], (u32)__popcll(m1));
             }
-        } else if (k < nkeys) {
-            atomicAdd(&cnt[0][r], 1u);
+        } else if (r >= 0) {
+            atomicAdd(&cnt0[r], 1u);
+        }
+    };
+    if constexpr (REG) {
+#pragma unroll
+        for (int j = 0; j < QT_KPT; j++) {
+            if (j * QT_THREADS < nkeys) {  // uniform
+                const int k = tid + j * QT_THREADS;
+                const int r = k < nkeys ? (int)((float)ORBX_PX(rkey[j]) / hX) : -1;
+                rnode[j] = (u32)r;
+                count_root(r);
+            }
+        }
+    } else {
+        for (int k0 = 0; k0 < nkeys; k0 += QT_THREADS) {
+            const int k = k0 + tid;
+            const int r = k < nkeys ? (int)((float)ORBX_PX(kp[k]) / hX) : -1;
+            if (k < nkeys) kn[k] = (u16)r;
+            count_root(r);
         }
     }
     __syncthreads();
@@ -1872,7 +1915,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         // compact non-empty roots, keeping order; moved[r] = list position
         int L = 0;
         for (int r = 0; r < nIni; r++) {
-            const u32 c = cnt[0][r];
+            const u32 c = cnt0[r];
             if (c > 0) {
                 moved[r] = (u16)L;
                 short4 b;
@@ -1880,9 +1923,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 b.y = (short)(int)(hX * (float)(r + 1));
                 b.z = 0;
                 b.w = (short)ySpan;
-                box[1][L] = b;
-                cnt[1][L] = c;
-                seq[1][L] = (u32)r;
+                box1[L] = b;
+                cnt1[L] = c;
+                seq1[L] = (u32)r;
                 L++;
             }
         }
@@ -1896,14 +1939,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     // at the end of a pass for the next one), so a pass sweeps the keys once, not twice.
     for (int i = tid; i < S.L * 4; i += QT_THREADS) childCnt[i] = 0;
     __syncthreads();
-    for (int k0 = 0; k0 < nkeys; k0 += QT_THREADS) {
-        const int k = k0 + tid;
-        int code = -1;  // node * 4 + quadrant of a key that is counted
-        if (k < nkeys) {
-            const int nd = moved[kn[k]];
-            kn[k] = (u16)nd;
-            if (cnt[1][nd] > 1) code = nd * 4 + child_quadrant(kp[k], box[1][nd]);
-        }
+    auto count_code = [&](int code) {  // code = node * 4 + quadrant of a key that is counted, or -1
         if (fewRoots) {
 #pragma unroll
             for (int c = 0; c < 8; c++) {
@@ -1912,6 +1948,32 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
             }
         } else if (code >= 0) {
             atomicAdd(&childCnt[code], 1u);
+        }
+    };
+    if constexpr (REG) {
+#pragma unroll
+        for (int j = 0; j < QT_KPT; j++) {
+            if (j * QT_THREADS < nkeys) {
+                const int k = tid + j * QT_THREADS;
+                int code = -1;
+                if (k < nkeys) {
+                    const int nd = moved[rnode[j]];
+                    rnode[j] = (u32)nd;
+                    if (cnt1[nd] > 1) code = nd * 4 + child_quadrant(rkey[j], box1[nd]);
+                }
+                count_code(code);
+            }
+        }
+    } else {
+        for (int k0 = 0; k0 < nkeys; k0 += QT_THREADS) {
+            const int k = k0 + tid;
+            int code = -1;
+            if (k < nkeys) {
+                const int nd = moved[kn[k]];
+                kn[k] = (u16)nd;
+                if (cnt1[nd] > 1) code = nd * 4 + child_quadrant(kp[k], box1[nd]);
+            }
+            count_code(code);
         }
     }
     int cur = 1;  // buffer holding the current list
@@ -1923,10 +1985,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     for (int iter = 0; iter < 64; iter++) {
         const int L = S.L;
         const int careful = S.careful;
-        const short4* cb = box[cur];
-        const u32* ccnt = cnt[cur];
-        const u32* cseq = seq[cur];
+        const short4* cb = (cur ? box1 : box0);
+        const u32* ccnt = (cur ? cnt1 : cnt0);
+        const u32* cseq = (cur ? seq1 : seq0);
         const int nxt = cur ^ 1;
+        short4* const xb = nxt ? box1 : box0;
+        u32* const xcnt = nxt ? cnt1 : cnt0;
+        u32* const xseq = nxt ? seq1 : seq0;
         // (childCnt holds the quadrant counts of this pass's nodes: gathered when the keys were moved here)
         // processing order of expandable nodes
         int C = 0;
@@ -2064,9 +2129,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                 const int np = tnew + stay + off;
                 moved[i] = (u16)np;
                 if (np < lcap) {
-                    box[nxt][np] = cb[i];
-                    cnt[nxt][np] = ccnt[i];
-                    seq[nxt][np] = cseq[i];
+                    xb[np] = cb[i];
+                    xcnt[np] = ccnt[i];
+                    xseq[np] = cseq[i];
                 }
             }
             stay += tot;
@@ -2083,9 +2148,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
                         const int np = tnew - 1 - gidx;
                         newId[i * 4 + q] = (u16)np;
                         if (np < lcap) {
-                            box[nxt][np] = child_box(cb[i], q);
-                            cnt[nxt][np] = c;
-                            seq[nxt][np] = nextSeq + (u32)gidx;
+                            xb[np] = child_box(cb[i], q);
+                            xcnt[np] = c;
+                            xseq[np] = nextSeq + (u32)gidx;
                         }
                         if (c > 1) expand++;
                         gidx++;
@@ -2107,8 +2172,24 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
         // keys move to their nodes of the next list and are counted into the quadrants of those nodes;
         // four keys per trip: the loads of a trip are issued together, so a thread waits for memory once
         // per four keys
-        const short4* nb = box[nxt];
-        const u32* ncnt = cnt[nxt];
+        const short4* nb = xb;
+        const u32* ncnt = xcnt;
+        if constexpr (REG) {
+#pragma unroll
+            for (int j = 0; j < QT_KPT; j++) {
+                if (tid + j * QT_THREADS < nkeys) {
+                    const int nd = (int)rnode[j];
+                    const u16 r = rankOf[nd];
+                    int to;
+                    if (r != 0xFFFF && r < nproc)
+                        to = newId[nd * 4 + child_quadrant(rkey[j], cb[nd])];
+                    else
+                        to = moved[nd];
+                    rnode[j] = (u32)to;
+                    if (to < nextL && ncnt[to] > 1) atomicAdd(&childCnt[to * 4 + child_quadrant(rkey[j], nb[to])], 1u);
+                }
+            }
+        } else
         for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
             int nd[4];
             u32 key[4];
@@ -2157,6 +2238,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     u64* best = (u64*)childCnt;
     for (int i = tid; i < L; i += QT_THREADS) best[i] = 0;
     __syncthreads();
+    if constexpr (REG) {
+#pragma unroll
+        for (int j = 0; j < QT_KPT; j++) {
+            const int k = tid + j * QT_THREADS;
+            if (k < nkeys) atomicMax(&best[rnode[j]], ((u64)ORBX_PR(rkey[j]) << 32) | (u64)(0xFFFFFFFFu - (u32)k));
+        }
+    } else
     for (int k0 = tid; k0 < nkeys; k0 += 4 * QT_THREADS) {
         int nd[4];
         u32 key[4];
@@ -2180,6 +2268,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(Geom g, const u32* __re
     }
     QT_MARK("best");
     if (tid == 0) *selCnt = L;
+    };
+    if (nkeys <= QT_THREADS * QT_KPT)  // the same for every thread
+        subdivide(std::true_type{});
+    else
+        subdivide(std::false_type{});
 }
 
 // ------------------------------------------------------------------ describe
@@ -3707,8 +3800,8 @@ bool is_pinned_host(const void* p) {
 // the workers copy them to the caller's arrays: the host copy of pass k + 1, the upload of pass k, the
 // kernels of pass k - 1 and the download of pass k - 2 run side by side.  Images and output arrays that are
 // already page-locked (hipHostMalloc / hipHostRegister, orbx_register_host) skip the host copies.
-int extract_host_pipelined(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh, size_t row_stride, size_t img_stride,
-                           orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out, int chunk) {
+int extract_host_passes(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh, size_t row_stride, size_t img_stride,
+                        orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out, int chunk) {
     const size_t sp = (size_t)align_up(w, 64);  // staged rows are padded to 64 bytes: aligned word loads everywhere
     const size_t inBytes = (size_t)chunk * sp * hh;
     const size_t kpBytes = (size_t)chunk * cap * sizeof(orbx_keypoint), dsBytes = (size_t)chunk * cap * 32;
@@ -3831,6 +3924,18 @@ int extract_host_pipelined(orbx_handle* h, const uint8_t* imgs, int B, int w, in
     for (int k = npass; k < npass + S; k++)
         if ((rc = deliver(h->hostSlots[k % S]))) return rc;
     return check_device_error(h);
+}
+
+int extract_host_pipelined(orbx_handle* h, const uint8_t* imgs, int B, int w, int hh, size_t row_stride, size_t img_stride,
+                           orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out, int chunk) {
+    const int rc = extract_host_passes(h, imgs, B, w, hh, row_stride, img_stride, kps, desc, cap, n_out, chunk);
+    if (rc != ORBX_OK) {
+        // a pass failed with copies of its neighbours still in flight: nothing of this call may touch the
+        // slots or the caller's arrays once it has returned
+        (void)hipDeviceSynchronize();
+        for (auto& H : h->hostSlots) H.busy = false;
+    }
+    return rc;
 }
 
 }  // namespace
