@@ -453,7 +453,9 @@ struct PyramidLevel {
 struct PyramidArgs {
     PyramidLevel lv[ORBX_MAX_LEVELS];
 };
+#ifndef PYR_WAVES
 #define PYR_WAVES 16
+#endif
 #ifdef ORBX_PYR_DIAG
 // Diagnostic build only (tools/probe/pyr_phases.py): per frame, wave and level three s_memtime stamps
 // (level start, walk done, barrier passed).
