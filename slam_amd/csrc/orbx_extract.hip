@@ -1280,6 +1280,8 @@ struct FastGroup {
     int recBegin, nCells;                       // this group's slice of the cell records
     int roiPitch, planeOff, queueOff, ldsBytes;  // ROI rows | strength plane (also the word queue) | pixel queue
     u32 roiMagic;                               // div_magic(roiPitch)
+    int copyRows;                               // ROI rows per load instruction of the copy: 64 / (roiPitch / 4)
+    u32 copyMagic;                              // div_magic(roiPitch / 4)
 };
 
 // v_pk_minimum3_f16 / v_pk_maximum3_f16: three-input minimum / maximum on both 16-bit halves.
@@ -1349,11 +1351,7 @@ __device__ unsigned long long* d_fastDiag;
 // reference's per-cell fallback).  A single wave executes LDS operations in program order,
 // so the phases need no workgroup barrier beyond the compiler-level ordering of
 // __syncthreads().
-#define FAST_CPW 1  // cells per wave: the ROI of the next cell is fetched into registers while the current one is worked on
-
-struct __attribute__((packed, aligned(4))) FastPair {
-    u32 a, b;
-};
+#define FAST_CPW 1  // cells per wave
 
 template <int RPC>
 __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligned, const u8* __restrict__ pyr,
@@ -1363,7 +1361,6 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
     // LDS_U8 / LDS_U32 take LDS addresses: the array's own address (a link-time constant, 0 while it is
     // the kernel's only LDS object) is folded into every base register below, at no cost
     const u32 L0 = (u32)(size_t)(const __attribute__((address_space(3))) u8*)lds;
-    u8* roi = lds;
     u8* plane = lds + grp.planeOff;
     u32* wq = (u32*)plane;  // the word queue is dead before the plane is cleared
     u16* queue = (u16*)(lds + grp.queueOff);
@@ -1375,88 +1372,46 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
     // RPC = the ROI row pitch as a compile-time constant (0: taken from the geometry): with a constant
     // pitch every ring, neighbour and row access below is one base register plus an immediate offset
     const int RP = RPC ? RPC : grp.roiPitch;
+    (void)img0Aligned;  // the copy below takes any source alignment
 #ifdef ORBX_FAST_DIAG
     unsigned long long diagT[5] = {0, 0, 0, 0, 0}, diagLast = __builtin_amdgcn_s_memtime();
     int diagN1 = 0, diagN2 = 0, diagPass2 = 0, diagNW = 0, diagTotal = 0;
 #endif
-    // ROI -> LDS for cells whose source rows are 4-byte aligned: ROI column c lands on byte c + 1 of
-    // its LDS row, so word wd of a row is the source bytes from xa + 4 * (wd - 1) + so + 3 on, taken
-    // from two aligned source words.  A lane copies word wd of row lw of every group of rowsW rows.
-    // issue() requests the first 8 groups into registers (one memory round trip for an ordinary
-    // cell); land() shifts them into LDS and fetches what is left of a very tall cell directly.
-    auto aligned = [&](const FastCell& C) { return (C.w[0] & 255u) > 0u || img0Aligned != 0; };
-    auto source = [&](const FastCell& C, int* pitch) {
-        const u32 t = (C.w[0] >> 24) + 3u;
-        const u8* sbase;
+    // ROI -> LDS: ROI column c lands on byte c + 1 of its LDS row, i.e. word wd of LDS row y holds the level's
+    // bytes (iniX - 1 + 4 * wd ...) of row iniY + y.  The words go from global memory straight into the LDS
+    // (direct-to-LDS loads take any byte address, so the shift that puts interior pixel 0 on a word boundary
+    // costs nothing and source rows need no alignment): lane = (row lw, word wd) of a group of copyRows rows,
+    // a group per load instruction, its 64 words consecutive in the LDS.  No registers, no vector ALU work
+    // beyond the lane's offset.
+    const int cpW = RP >> 2, cpRows = RPC ? 64 / (RPC ? RPC >> 2 : 1) : grp.copyRows;
+    const int cpLw = (int)fastdiv((u32)lane, (u32)cpW, RPC ? div_magic((u32)(RPC ? RPC >> 2 : 1)) : grp.copyMagic), cpWd = lane - cpLw * cpW;
+    auto copy_roi = [&](const FastCell& C) {
+        const int rh = (C.w[0] >> 16) & 255, nWc = (int)(C.w[7] & 255);
+        const u8* sb;
+        int pitch;
         if ((C.w[0] & 255u) > 0u) {
-            *pitch = (int)C.w[9];
-            sbase = pyr + (i64)f * g.pyrFrameBytes + C.w[8];
+            pitch = (int)C.w[9];
+            sb = pyr + (i64)f * g.pyrFrameBytes + C.w[8] + (i64)(C.w[0] >> 24) - 1;
         } else {
-            *pitch = img0.pitch;
-            sbase = img0.base + (i64)f * img0.frameStride + (i64)(C.w[1] >> 16) * img0.pitch + ((C.w[1] & 0xffff) & ~3u);
+            pitch = img0.pitch;
+            sb = img0.base + (i64)f * img0.frameStride + (i64)(C.w[1] >> 16) * img0.pitch + (i64)(C.w[1] & 0xffff) - 1;
         }
-        // the first source word of LDS word 0 may lie one word before the aligned ROI start: that
-        // signed constant goes into the uniform base, so the 32-bit lane offsets never go negative
-        return sbase + 4 * ((int)(t >> 2) - 1);
-    };
-    auto issue = [&](const FastCell& C, FastPair (&v)[8]) {
-        const int nWc = (int)(C.w[7] & 255), rowsW = (int)((C.w[7] >> 8) & 255);
-        const int lw = (int)fastdiv((u32)lane, (u32)nWc, C.w[5]), wd = lane - lw * nWc;
-        if (lw < rowsW) {
-            int pitch;
-            const u8* sbase = source(C, &pitch);
-            u32 soff = mul24((u32)lw, (u32)pitch) + 4u * (u32)wd;
-            const u32 sStep = (u32)(rowsW * pitch);
-            // groups 0 .. nFull-1 hold a row for every copying lane, group nFull for lanes lw < rem: the
-            // first kind needs no per-lane test (wave-uniform branch)
-            const int nFull = (int)(C.w[11] & 255u), rem = (int)((C.w[11] >> 8) & 255u);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (k < nFull) {
-                    v[k] = *(const FastPair*)(sbase + soff);
-                } else if (k == nFull) {
-                    if (lw < rem) v[k] = *(const FastPair*)(sbase + soff);
-                }
-                soff += sStep;
+        if (cpLw < cpRows && cpWd < nWc) {
+            u32 voff = mul24((u32)cpLw, (u32)pitch) + 4u * (u32)cpWd;
+            const u32 vstep = (u32)(cpRows * pitch);
+            for (int y0 = 0; y0 < rh; y0 += cpRows) {  // uniform
+                // a whole group of rows needs no per-lane test
+                if (y0 + cpRows <= rh || cpLw < rh - y0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + (size_t)voff),
+                                                     (__attribute__((address_space(3))) void*)(size_t)(L0 + (u32)(y0 * RP)), 4, 0, 0);
+                voff += vstep;
             }
         }
-    };
-    auto land = [&](const FastCell& C, const FastPair (&v)[8]) {
-        const int rh = (C.w[0] >> 16) & 255;
-        const u32 sh = ((C.w[0] >> 24) + 3u) & 3u;
-        const int nWc = (int)(C.w[7] & 255), rowsW = (int)((C.w[7] >> 8) & 255);
-        const int lw = (int)fastdiv((u32)lane, (u32)nWc, C.w[5]), wd = lane - lw * nWc;
-        if (lw < rowsW) {
-            u32 doff = L0 + mul24((u32)lw, (u32)RP) + 4u * (u32)wd;
-            const u32 dStep = (u32)(rowsW * RP);
-            const int nFull = (int)(C.w[11] & 255u), rem = (int)((C.w[11] >> 8) & 255u);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (k < nFull) {
-                    LDS_U32W(doff) = __builtin_amdgcn_alignbyte(v[k].b, v[k].a, sh);
-                } else if (k == nFull) {
-                    if (lw < rem) LDS_U32W(doff) = __builtin_amdgcn_alignbyte(v[k].b, v[k].a, sh);
-                }
-                doff += dStep;
-            }
-            if (8 * rowsW < rh) {  // wave-uniform: cells taller than 8 groups
-                int pitch;
-                const u8* sbase = source(C, &pitch);
-                u32 soff = mul24((u32)(lw + 8 * rowsW), (u32)pitch) + 4u * (u32)wd;
-                const u32 sStep = (u32)(rowsW * pitch);
-                for (int y = lw + 8 * rowsW; y < rh; y += rowsW) {
-                    const FastPair w = *(const FastPair*)(sbase + soff);
-                    LDS_U32W(doff) = __builtin_amdgcn_alignbyte(w.b, w.a, sh);
-                    soff += sStep;
-                    doff += dStep;
-                }
-            }
-        }
+        // direct-to-LDS loads are not LDS writes to the compiler: wait for them here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     FastCell C = cells[min(rec0, recEnd - 1)];
-    FastPair pre[8];
-    if (aligned(C)) issue(C, pre);
     for (int ci = 0; ci < FAST_CPW; ci++) {
         const int rec = rec0 + ci;
         if (rec >= recEnd) break;
@@ -1468,23 +1423,9 @@ __global__ __launch_bounds__(64) void k_fast(Geom g, ImgRef img0, int img0Aligne
         const int iw = rw - 6, ih = rh - 6;
         const int nk = (int)((C.w[3] >> 16) & 255), rowsPer = (int)(C.w[3] >> 24);
         __syncthreads();  // the previous cell's phases are through with the LDS
-        if (!empty) {
-            if (aligned(C)) {
-                land(C, pre);
-            } else {
-                const u32 mg = C.w[10];
-                const int iniX = C.w[1] & 0xffff, iniY = C.w[1] >> 16;
-                const u8* srow = img0.base + (i64)f * img0.frameStride + (i64)iniY * img0.pitch + iniX;
-                for (int i = lane; i < rw * rh; i += 64) {
-                    const int y = fastdiv(i, rw, mg), x = i - y * rw;
-                    roi[y * RP + 1 + x] = srow[mul24((u32)y, (u32)img0.pitch) + x];
-                }
-            }
-        }
+        if (!empty) copy_roi(C);
         __syncthreads();
-        // request the next cell's ROI now: it arrives while this cell is worked on
         const FastCell Cn = cells[min(rec + 1, recEnd - 1)];
-        if (ci + 1 < FAST_CPW && rec + 1 < recEnd && aligned(Cn)) issue(Cn, pre);
         FAST_STAMP(0);
         if (empty) {
             if (lane == 0) *cnt = 0;
@@ -3035,6 +2976,8 @@ int compute_geometry(orbx_handle* h, int w, int hh) {
             memset(&G, 0, sizeof(G));
             G.roiPitch = std::max(4 * ((mw_ + 3) / 4 + 2), minPitch);
             G.roiMagic = div_magic((u32)G.roiPitch);
+            G.copyRows = std::max(64 / (G.roiPitch / 4), 1);  // (cells are at most 59 + 6 pixels wide: 19 words)
+            G.copyMagic = div_magic((u32)(G.roiPitch / 4));
             G.planeOff = align_up(G.roiPitch * (mh_ + 6), 16);
             G.queueOff = G.planeOff + align_up(G.roiPitch * (mh_ + 6), 16);
             G.ldsBytes = G.queueOff + align_up(2 * mw_ * mh_ + 8, 16);
